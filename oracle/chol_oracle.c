@@ -1,0 +1,538 @@
+/*
+ * chol_oracle.c -- CPU restatement of the reference's tiled-Cholesky hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under dense_linear_app_amd/ (the product)
+ * may import, link or call this file.  Allowed users: tests/, the smoke check in
+ * __graft_entry__.smoke(), and bench.py's `cpu_baseline` leg (as the thing
+ * timed *beside* the GPU number, never as the thing shipped).
+ *
+ * PARITY STATUS
+ *   - Input construction (SPD generator, dominance pass, tile cutter): PINNED.
+ *     The functions below are checked bit-for-bit against the reference's own
+ *     functions (client_distrib.cpp:224-321) compiled from /root/reference by
+ *     oracle/build_ref.sh into oracle/_ref/, and against the golden vectors in
+ *     tests/golden/ that were produced by that build.
+ *   - Tile arithmetic (POTRF/TRSM/SYRK/GEMM): PARITY UNPINNED.  The reference
+ *     does no arithmetic of its own: it calls Chameleon (unpinned git HEAD) ->
+ *     StarPU 1.4 -> OpenBLAS 0.3.26 / cuBLAS (Dockerfile.worker.v4:24,48,60),
+ *     none of which is in /root/reference, and it holds no golden vectors or
+ *     valid numerical tests for this path.  What is
+ *     restated here is the *published* BLAS/LAPACK definition of the four
+ *     calls with the exact flag sets the worker uses (worker_distrib.cpp:238,
+ *     323, 416, 511).  tests/ cross-check it against scipy's bundled OpenBLAS
+ *     (same library family) via committed fixtures.
+ *
+ * All matrices are column-major.  Reference citations are relative to
+ * /root/reference/ ; W2 = cholesky_armonik/w_c_cons_v2/worker_construction2/
+ * src/worker_distrib.cpp, C2 = cholesky_armonik/w_c_cons_v2/
+ * client_construction2/client/src/client_distrib.cpp, C1 = the v1 client,
+ * V6 = Cholesky_chameleon_VM/cho/docker_installation_and_bench_files/v6_test.c,
+ * REMIX = Cholesky_chameleon_VM/cho/Cholesky_Chameleon_sauv/code_c/
+ * lapack_dpotrf_remix_c.c.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+/* runtime ISA dispatch: the prebuilt .so travels to a different host */
+#define ORC_HOT __attribute__((target_clones("avx512f", "fma", "default")))
+
+/* ------------------------------------------------------------------------ */
+/* std::mt19937_64 (C2:230) -- Matsumoto/Nishimura MT19937-64                */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t mt[312];
+  int idx;
+} orc_mt64;
+
+static void mt64_seed(orc_mt64 *g, uint64_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 312; ++i)
+    g->mt[i] = 6364136223846793005ULL * (g->mt[i - 1] ^ (g->mt[i - 1] >> 62)) + (uint64_t)i;
+  g->idx = 312;
+}
+
+static uint64_t mt64_next(orc_mt64 *g) {
+  if (g->idx >= 312) {
+    const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL, MA = 0xB5026F5AA96619E9ULL;
+    for (int i = 0; i < 312; ++i) {
+      uint64_t x = (g->mt[i] & UM) | (g->mt[(i + 1) % 312] & LM);
+      g->mt[i] = g->mt[(i + 156) % 312] ^ (x >> 1) ^ ((x & 1ULL) ? MA : 0ULL);
+    }
+    g->idx = 0;
+  }
+  uint64_t x = g->mt[g->idx++];
+  x ^= (x >> 29) & 0x5555555555555555ULL;
+  x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+  x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+  x ^= (x >> 43);
+  return x;
+}
+
+/* std::uniform_real_distribution<double>(-0.5, 0.5) as libstdc++ evaluates it
+ * (C2:231): one 64-bit draw, canonical = double(u) / 2^64 clipped below 1. */
+static double mt64_uniform_pm_half(orc_mt64 *g) {
+  double r = (double)mt64_next(g) / 18446744073709551616.0;
+  if (r >= 1.0) r = nextafter(1.0, 0.0);
+  return r * (0.5 - (-0.5)) + (-0.5);
+}
+
+ORC_API void orc_mt64_draws(uint64_t seed, int n, uint64_t *out) {
+  orc_mt64 g;
+  mt64_seed(&g, seed);
+  for (int i = 0; i < n; ++i) out[i] = mt64_next(&g);
+}
+
+/* make_spd_like_chameleon (C2:224-252) */
+ORC_API void orc_make_spd_like_chameleon(double *A, int N, int LDA, double bump, char uplo,
+                                         uint64_t seed) {
+  orc_mt64 g;
+  mt64_seed(&g, seed);
+#define IDX(i, j) ((size_t)(i) + (size_t)(j) * (size_t)LDA)
+  if (uplo == 'L' || uplo == 'l') {
+    for (int j = 0; j < N; ++j)
+      for (int i = j; i < N; ++i) A[IDX(i, j)] = mt64_uniform_pm_half(&g);
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < j; ++i) A[IDX(i, j)] = A[IDX(j, i)];
+  } else {
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i <= j; ++i) A[IDX(i, j)] = mt64_uniform_pm_half(&g);
+    for (int j = 0; j < N; ++j)
+      for (int i = j + 1; i < N; ++i) A[IDX(i, j)] = A[IDX(j, i)];
+  }
+  for (int i = 0; i < N; ++i) A[IDX(i, i)] += bump;
+}
+
+/* enforce_strict_diag_dominance (C2:255-264); row sum in j = 0..N-1 order */
+ORC_API void orc_enforce_strict_diag_dominance(double *A, int N, int LDA, double eps) {
+  for (int i = 0; i < N; ++i) {
+    double s = 0.0;
+    for (int j = 0; j < N; ++j)
+      if (j != i) s += fabs(A[IDX(i, j)]);
+    double need = s + eps - A[IDX(i, i)];
+    if (need > 0.0) A[IDX(i, i)] += need;
+  }
+}
+#undef IDX
+
+/* extract_block_from_spd_matrix_colmajor (C2:280-309): zero-padded B x B tile */
+ORC_API void orc_extract_block(const double *A, int N, int LDA, int B, int bi, int bj,
+                               double *block) {
+  memset(block, 0, sizeof(double) * (size_t)B * (size_t)B);
+  const int r0 = bi * B, c0 = bj * B;
+  for (int jj = 0; jj < B; ++jj) {
+    int cj = c0 + jj;
+    if (cj >= N) continue;
+    for (int ii = 0; ii < B; ++ii) {
+      int ri = r0 + ii;
+      if (ri >= N) break;
+      block[(size_t)ii + (size_t)jj * B] = A[(size_t)ri + (size_t)cj * LDA];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Throughput-run generator: CHAMELEON_dplgsy_Tile stand-in    */
+/* (V6:46, bump = N, seed 42).  Counter-based, so any tile of any layout on  */
+/* any number of GPUs sees the same matrix.  The product's device kernel     */
+/* (csrc/cholmi_gen.hip) must produce exactly these bits.                    */
+/* ------------------------------------------------------------------------ */
+static inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+ORC_API double orc_plgsy_entry(double bump, uint64_t seed, int64_t i, int64_t j) {
+  uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+  uint64_t h = splitmix64(splitmix64(seed ^ (hi << 32 | lo)) + lo);
+  double v = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  return (i == j) ? v + bump : v;
+}
+
+/* Fill a tile-layout matrix (tile (I,J) at ((I + J*Nb) * B*B), column-major
+ * inside, ld = B: the Chameleon descriptor layout of V6:44 with lm=ln=N). */
+ORC_API void orc_plgsy_tiles(double *T, int Nb, int B, double bump, uint64_t seed) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int J = 0; J < Nb; ++J)
+    for (int I = 0; I < Nb; ++I) {
+      double *t = T + ((size_t)I + (size_t)J * Nb) * (size_t)B * B;
+      for (int jj = 0; jj < B; ++jj)
+        for (int ii = 0; ii < B; ++ii)
+          t[ii + (size_t)jj * B] =
+              orc_plgsy_entry(bump, seed, (int64_t)I * B + ii, (int64_t)J * B + jj);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Tile kernels: BLAS/LAPACK definitions with the worker's flag sets         */
+/* ------------------------------------------------------------------------ */
+
+/* C += alpha * A * B^T ; A is m x k, B is n x k, column-major. */
+ORC_HOT static void gemm_nt_acc(int m, int n, int k, double alpha, const double *restrict A,
+                                int lda, const double *restrict B, int ldb,
+                                double *restrict C, int ldc) {
+  enum { MB = 256, KB = 128 };
+  for (int m0 = 0; m0 < m; m0 += MB) {
+    const int mm = (m - m0 < MB) ? m - m0 : MB;
+    for (int k0 = 0; k0 < k; k0 += KB) {
+      const int kk = (k - k0 < KB) ? k - k0 : KB;
+      int j = 0;
+      for (; j + 4 <= n; j += 4) {
+        double *restrict c0 = C + m0 + (size_t)(j + 0) * ldc;
+        double *restrict c1 = C + m0 + (size_t)(j + 1) * ldc;
+        double *restrict c2 = C + m0 + (size_t)(j + 2) * ldc;
+        double *restrict c3 = C + m0 + (size_t)(j + 3) * ldc;
+        int p = 0;
+        for (; p + 4 <= kk; p += 4) {
+          const double *restrict a0 = A + m0 + (size_t)(k0 + p + 0) * lda;
+          const double *restrict a1 = A + m0 + (size_t)(k0 + p + 1) * lda;
+          const double *restrict a2 = A + m0 + (size_t)(k0 + p + 2) * lda;
+          const double *restrict a3 = A + m0 + (size_t)(k0 + p + 3) * lda;
+          double b[4][4];
+          for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r)
+              b[q][r] = alpha * B[(size_t)(j + r) + (size_t)(k0 + p + q) * ldb];
+          for (int i = 0; i < mm; ++i) {
+            const double x0 = a0[i], x1 = a1[i], x2 = a2[i], x3 = a3[i];
+            c0[i] += x0 * b[0][0] + x1 * b[1][0] + x2 * b[2][0] + x3 * b[3][0];
+            c1[i] += x0 * b[0][1] + x1 * b[1][1] + x2 * b[2][1] + x3 * b[3][1];
+            c2[i] += x0 * b[0][2] + x1 * b[1][2] + x2 * b[2][2] + x3 * b[3][2];
+            c3[i] += x0 * b[0][3] + x1 * b[1][3] + x2 * b[2][3] + x3 * b[3][3];
+          }
+        }
+        for (; p < kk; ++p) {
+          const double *restrict a0 = A + m0 + (size_t)(k0 + p) * lda;
+          const double b0 = alpha * B[(size_t)(j + 0) + (size_t)(k0 + p) * ldb];
+          const double b1 = alpha * B[(size_t)(j + 1) + (size_t)(k0 + p) * ldb];
+          const double b2 = alpha * B[(size_t)(j + 2) + (size_t)(k0 + p) * ldb];
+          const double b3 = alpha * B[(size_t)(j + 3) + (size_t)(k0 + p) * ldb];
+          for (int i = 0; i < mm; ++i) {
+            const double x = a0[i];
+            c0[i] += x * b0;
+            c1[i] += x * b1;
+            c2[i] += x * b2;
+            c3[i] += x * b3;
+          }
+        }
+      }
+      for (; j < n; ++j) {
+        double *restrict c0 = C + m0 + (size_t)j * ldc;
+        for (int p = 0; p < kk; ++p) {
+          const double *restrict a0 = A + m0 + (size_t)(k0 + p) * lda;
+          const double b0 = alpha * B[(size_t)j + (size_t)(k0 + p) * ldb];
+          for (int i = 0; i < mm; ++i) c0[i] += a0[i] * b0;
+        }
+      }
+    }
+  }
+}
+
+static void scale_cols(int m, int n, double beta, double *C, int ldc, int lower_only) {
+  if (beta == 1.0) return;
+  for (int j = 0; j < n; ++j) {
+    int i0 = lower_only ? j : 0;
+    double *c = C + (size_t)j * ldc;
+    if (beta == 0.0)
+      for (int i = i0; i < m; ++i) c[i] = 0.0;
+    else
+      for (int i = i0; i < m; ++i) c[i] *= beta;
+  }
+}
+
+/* dgemm(NoTrans, Trans): C := alpha*A*B^T + beta*C  (W2:511 with alpha=-1, beta=1) */
+ORC_API void orc_dgemm_nt(int m, int n, int k, double alpha, const double *A, int lda,
+                          const double *B, int ldb, double beta, double *C, int ldc) {
+  scale_cols(m, n, beta, C, ldc, 0);
+  if (alpha != 0.0 && k > 0) gemm_nt_acc(m, n, k, alpha, A, lda, B, ldb, C, ldc);
+}
+
+/* dsyrk(Lower, NoTrans): C_lower := alpha*A*A^T + beta*C_lower (W2:416 with
+ * alpha=-1, beta=1).  The strict upper triangle of C is NOT referenced. */
+ORC_API void orc_dsyrk_ln(int n, int k, double alpha, const double *A, int lda, double beta,
+                          double *C, int ldc) {
+  enum { NB = 64 };
+  scale_cols(n, n, beta, C, ldc, 1);
+  if (alpha == 0.0 || k <= 0) return;
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int nb = (n - j0 < NB) ? n - j0 : NB;
+    /* diagonal block: column by column, rows j..end of the block only */
+    for (int j = j0; j < j0 + nb; ++j) {
+      double *c = C + (size_t)j * ldc;
+      for (int p = 0; p < k; ++p) {
+        const double *a = A + (size_t)p * lda;
+        const double b = alpha * a[j];
+        for (int i = j; i < j0 + nb; ++i) c[i] += a[i] * b;
+      }
+    }
+    /* strictly-below part of this block column */
+    const int mrest = n - (j0 + nb);
+    if (mrest > 0)
+      gemm_nt_acc(mrest, nb, k, alpha, A + j0 + nb, lda, A + j0, lda,
+                  C + (j0 + nb) + (size_t)j0 * ldc, ldc);
+  }
+}
+
+/* dtrsm(Right, Lower, Trans, NonUnit): B := alpha * B * L^{-T}  (W2:323,
+ * alpha = 1).  Only the lower triangle of L is referenced.  Blocked form of
+ * the reference-BLAS column sweep. */
+ORC_API void orc_dtrsm_rltn(int m, int n, double alpha, const double *L, int ldl, double *B,
+                            int ldb) {
+  enum { NB = 64 };
+  if (alpha != 1.0) scale_cols(m, n, alpha, B, ldb, 0);
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = (n - k0 < NB) ? n - k0 : NB;
+    for (int k = k0; k < k0 + nb; ++k) {
+      double *bk = B + (size_t)k * ldb;
+      const double t = 1.0 / L[(size_t)k + (size_t)k * ldl];
+      for (int i = 0; i < m; ++i) bk[i] *= t;
+      for (int j = k + 1; j < k0 + nb; ++j) {
+        const double l = L[(size_t)j + (size_t)k * ldl];
+        if (l != 0.0) {
+          double *bj = B + (size_t)j * ldb;
+          for (int i = 0; i < m; ++i) bj[i] -= l * bk[i];
+        }
+      }
+    }
+    const int nrest = n - (k0 + nb);
+    if (nrest > 0)
+      gemm_nt_acc(m, nrest, nb, -1.0, B + (size_t)k0 * ldb, ldb, L + (k0 + nb) + (size_t)k0 * ldl,
+                  ldl, B + (size_t)(k0 + nb) * ldb, ldb);
+  }
+}
+
+/* unblocked lower Cholesky of an n x n block (structure: REMIX:24-36, here
+ * column-major / right-looking inside the block).  info = 1-based index of
+ * the first non-positive (or NaN) pivot, as LAPACK dpotrf reports it. */
+static int potf2_lower(int n, double *A, int lda) {
+  for (int j = 0; j < n; ++j) {
+    double ajj = A[(size_t)j + (size_t)j * lda];
+    if (!(ajj > 0.0)) return j + 1;
+    ajj = sqrt(ajj);
+    A[(size_t)j + (size_t)j * lda] = ajj;
+    double *cj = A + (size_t)j * lda;
+    const double r = 1.0 / ajj;
+    for (int i = j + 1; i < n; ++i) cj[i] *= r;
+    for (int c = j + 1; c < n; ++c) {
+      const double l = cj[c];
+      double *cc = A + (size_t)c * lda;
+      for (int i = c; i < n; ++i) cc[i] -= cj[i] * l;
+    }
+  }
+  return 0;
+}
+
+/* dpotrf(Lower) on one tile (W2:238, V6:56): left-looking blocked as LAPACK
+ * dpotrf / REMIX:11-52; strict upper triangle is not referenced. */
+ORC_API int orc_dpotrf_lower(int n, double *A, int lda) {
+  enum { NB = 64 };
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int nb = (n - j0 < NB) ? n - j0 : NB;
+    /* A[j0:,j0:j0+nb] -= A[j0:,0:j0] * A[j0:j0+nb,0:j0]^T (diag block lower only) */
+    if (j0 > 0) {
+      orc_dsyrk_ln(nb, j0, -1.0, A + j0, lda, 1.0, A + j0 + (size_t)j0 * lda, lda);
+      const int mrest = n - (j0 + nb);
+      if (mrest > 0)
+        gemm_nt_acc(mrest, nb, j0, -1.0, A + j0 + nb, lda, A + j0, lda,
+                    A + (j0 + nb) + (size_t)j0 * lda, lda);
+    }
+    int info = potf2_lower(nb, A + j0 + (size_t)j0 * lda, lda);
+    if (info) return j0 + info;
+    const int mrest = n - (j0 + nb);
+    if (mrest > 0)
+      orc_dtrsm_rltn(mrest, nb, 1.0, A + j0 + (size_t)j0 * lda, lda,
+                     A + (j0 + nb) + (size_t)j0 * lda, lda);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The wave DAG (C2:506-565 / C1:278-333) over a tile-layout matrix:         */
+/* POTRF(k,k); TRSM(i,k) i>k; then SYRK(i,i,k) | GEMM(i,j,k) for k<j<=i.     */
+/* Tile (I,J) at T + (I + J*Nb)*B*B, ld = B.  Tasks of one wave phase are    */
+/* independent (C2:525-562) and run under OpenMP; phases are barriers.      */
+/* Returns 0 or the 1-based global index of the failing pivot.              */
+/* ------------------------------------------------------------------------ */
+ORC_API int orc_tiled_potrf_lower(double *T, int Nb, int B, int nthreads) {
+  const size_t bs = (size_t)B * B;
+#define TILE(I, J) (T + ((size_t)(I) + (size_t)(J) * Nb) * bs)
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  for (int k = 0; k < Nb; ++k) {
+    int info = orc_dpotrf_lower(B, TILE(k, k), B);
+    if (info) return k * B + info;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = k + 1; i < Nb; ++i) orc_dtrsm_rltn(B, B, 1.0, TILE(k, k), B, TILE(i, k), B);
+    const int nt = Nb - k - 1;
+    const long ntask = (long)nt * (nt + 1) / 2;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long t = 0; t < ntask; ++t) {
+      /* row-major enumeration of the lower triangle: t -> (ii >= jj) */
+      long ii = (long)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
+      while (ii * (ii + 1) / 2 > t) --ii;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+      const long jj = t - ii * (ii + 1) / 2;
+      const int i = k + 1 + (int)ii, j = k + 1 + (int)jj;
+      if (i == j)
+        orc_dsyrk_ln(B, B, -1.0, TILE(i, k), B, 1.0, TILE(i, i), B);
+      else
+        orc_dgemm_nt(B, B, B, -1.0, TILE(i, k), B, TILE(j, k), B, 1.0, TILE(i, j), B);
+    }
+  }
+#undef TILE
+  return 0;
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------ */
+/* Layout helpers and the (correct) residual the reference intended (V6:72-87*/
+/* computes L^T L by mistake -- SURVEY section 4): ||tril(L)tril(L)^T - A||_F / ||A||_F */
+/* ------------------------------------------------------------------------ */
+ORC_API void orc_lapack_to_tile(const double *A, int N, int LDA, int B, double *T) {
+  const int Nb = (N + B - 1) / B;
+  for (int J = 0; J < Nb; ++J)
+    for (int I = 0; I < Nb; ++I)
+      orc_extract_block(A, N, LDA, B, I, J, T + ((size_t)I + (size_t)J * Nb) * (size_t)B * B);
+}
+
+ORC_API void orc_tile_to_lapack(const double *T, int N, int LDA, int B, double *A) {
+  const int Nb = (N + B - 1) / B;
+  for (int J = 0; J < Nb; ++J)
+    for (int I = 0; I < Nb; ++I) {
+      const double *t = T + ((size_t)I + (size_t)J * Nb) * (size_t)B * B;
+      for (int jj = 0; jj < B && J * B + jj < N; ++jj)
+        for (int ii = 0; ii < B && I * B + ii < N; ++ii)
+          A[(size_t)(I * B + ii) + (size_t)(J * B + jj) * LDA] = t[ii + (size_t)jj * B];
+    }
+}
+
+/* Frobenius residual over the lower triangle + mirrored strict part.  L and A
+ * are N x N LAPACK layout; only tril(L) and tril(A) are read. */
+ORC_API double orc_residual_lower(const double *L, const double *A, int N, int LD) {
+  double num = 0.0, den = 0.0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : num, den)
+  for (int j = 0; j < N; ++j) {
+    for (int i = j; i < N; ++i) {
+      long double s = 0.0L;
+      for (int p = 0; p <= j; ++p)
+        s += (long double)L[(size_t)i + (size_t)p * LD] * (long double)L[(size_t)j + (size_t)p * LD];
+      const double a = A[(size_t)i + (size_t)j * LD];
+      const double d = (double)(s - (long double)a);
+      const double w = (i == j) ? 1.0 : 2.0;
+      num += w * d * d;
+      den += w * a * a;
+    }
+  }
+  return sqrt(num) / sqrt(den);
+}
+
+/* ------------------------------------------------------------------------ */
+/* fp32 variants of the four tile ops (BASELINE config 5): same definitions, */
+/* computed in float with the same loop order.                              */
+/* ------------------------------------------------------------------------ */
+ORC_HOT ORC_API void orc_sgemm_nt(int m, int n, int k, float alpha, const float *restrict A, int lda,
+                                  const float *restrict B, int ldb, float beta, float *restrict C,
+                                  int ldc) {
+  for (int j = 0; j < n; ++j) {
+    float *c = C + (size_t)j * ldc;
+    if (beta == 0.0f)
+      for (int i = 0; i < m; ++i) c[i] = 0.0f;
+    else if (beta != 1.0f)
+      for (int i = 0; i < m; ++i) c[i] *= beta;
+    for (int p = 0; p < k; ++p) {
+      const float *a = A + (size_t)p * lda;
+      const float b = alpha * B[(size_t)j + (size_t)p * ldb];
+      for (int i = 0; i < m; ++i) c[i] += a[i] * b;
+    }
+  }
+}
+
+ORC_HOT ORC_API void orc_ssyrk_ln(int n, int k, float alpha, const float *restrict A, int lda,
+                                  float beta, float *restrict C, int ldc) {
+  for (int j = 0; j < n; ++j) {
+    float *c = C + (size_t)j * ldc;
+    if (beta == 0.0f)
+      for (int i = j; i < n; ++i) c[i] = 0.0f;
+    else if (beta != 1.0f)
+      for (int i = j; i < n; ++i) c[i] *= beta;
+    for (int p = 0; p < k; ++p) {
+      const float *a = A + (size_t)p * lda;
+      const float b = alpha * a[j];
+      for (int i = j; i < n; ++i) c[i] += a[i] * b;
+    }
+  }
+}
+
+ORC_HOT ORC_API void orc_strsm_rltn(int m, int n, float alpha, const float *restrict L, int ldl,
+                                    float *restrict B, int ldb) {
+  if (alpha != 1.0f)
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < m; ++i) B[(size_t)i + (size_t)j * ldb] *= alpha;
+  for (int k = 0; k < n; ++k) {
+    float *bk = B + (size_t)k * ldb;
+    const float t = 1.0f / L[(size_t)k + (size_t)k * ldl];
+    for (int i = 0; i < m; ++i) bk[i] *= t;
+    for (int j = k + 1; j < n; ++j) {
+      const float l = L[(size_t)j + (size_t)k * ldl];
+      float *bj = B + (size_t)j * ldb;
+      for (int i = 0; i < m; ++i) bj[i] -= l * bk[i];
+    }
+  }
+}
+
+ORC_API int orc_spotrf_lower(int n, float *A, int lda) {
+  for (int j = 0; j < n; ++j) {
+    float ajj = A[(size_t)j + (size_t)j * lda];
+    if (!(ajj > 0.0f)) return j + 1;
+    ajj = sqrtf(ajj);
+    A[(size_t)j + (size_t)j * lda] = ajj;
+    float *cj = A + (size_t)j * lda;
+    const float r = 1.0f / ajj;
+    for (int i = j + 1; i < n; ++i) cj[i] *= r;
+    for (int c = j + 1; c < n; ++c) {
+      const float l = cj[c];
+      float *cc = A + (size_t)c * lda;
+      for (int i = c; i < n; ++i) cc[i] -= cj[i] * l;
+    }
+  }
+  return 0;
+}
+
+ORC_API int orc_tiled_spotrf_lower(float *T, int Nb, int B, int nthreads) {
+  const size_t bs = (size_t)B * B;
+#define TILE(I, J) (T + ((size_t)(I) + (size_t)(J) * Nb) * bs)
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  for (int k = 0; k < Nb; ++k) {
+    int info = orc_spotrf_lower(B, TILE(k, k), B);
+    if (info) return k * B + info;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = k + 1; i < Nb; ++i) orc_strsm_rltn(B, B, 1.0f, TILE(k, k), B, TILE(i, k), B);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int i = k + 1; i < Nb; ++i)
+      for (int j = k + 1; j < Nb; ++j) {
+        if (j > i) continue;
+        if (i == j)
+          orc_ssyrk_ln(B, B, -1.0f, TILE(i, k), B, 1.0f, TILE(i, i), B);
+        else
+          orc_sgemm_nt(B, B, B, -1.0f, TILE(i, k), B, TILE(j, k), B, 1.0f, TILE(i, j), B);
+      }
+  }
+#undef TILE
+  return 0;
+}

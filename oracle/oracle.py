@@ -1,0 +1,268 @@
+"""ctypes binding of oracle/libchol_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (dense_linear_app_amd) must never import this module.
+See the header of chol_oracle.c for what is and is not pinned to the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libchol_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libref_client.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="F_CONTIGUOUS")
+_dpc = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")  # 1-D buffers
+_fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="F_CONTIGUOUS")
+_fpc = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc).  Returns the .so path."""
+    src = os.path.join(_HERE, "chol_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libchol_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def build_ref() -> str | None:
+    """Compile the reference's own input functions (only where /root/reference exists)."""
+    if os.path.isdir(os.environ.get("REFERENCE_ROOT", "/root/reference")):
+        subprocess.check_call(["sh", os.path.join(_HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
+    return _REF_SO if os.path.exists(_REF_SO) else None
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_mt64_draws.argtypes = [C.c_uint64, C.c_int, np.ctypeslib.ndpointer(np.uint64)]
+        L.orc_make_spd_like_chameleon.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_char, C.c_uint64]
+        L.orc_enforce_strict_diag_dominance.argtypes = [_dp, C.c_int, C.c_int, C.c_double]
+        L.orc_extract_block.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.orc_plgsy_entry.argtypes = [C.c_double, C.c_uint64, C.c_int64, C.c_int64]
+        L.orc_plgsy_entry.restype = C.c_double
+        L.orc_plgsy_tiles.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
+        L.orc_dgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int,
+                                   C.c_double, _dp, C.c_int]
+        L.orc_dsyrk_ln.argtypes = [C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_double, _dp, C.c_int]
+        L.orc_dtrsm_rltn.argtypes = [C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int]
+        L.orc_dpotrf_lower.argtypes = [C.c_int, _dp, C.c_int]
+        L.orc_dpotrf_lower.restype = C.c_int
+        L.orc_tiled_potrf_lower.argtypes = [_dpc, C.c_int, C.c_int, C.c_int]
+        L.orc_tiled_potrf_lower.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
+        L.orc_lapack_to_tile.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dpc]
+        L.orc_tile_to_lapack.argtypes = [_dpc, C.c_int, C.c_int, C.c_int, _dp]
+        L.orc_residual_lower.argtypes = [_dp, _dp, C.c_int, C.c_int]
+        L.orc_residual_lower.restype = C.c_double
+        L.orc_sgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, _fp, C.c_int, _fp, C.c_int,
+                                   C.c_float, _fp, C.c_int]
+        L.orc_ssyrk_ln.argtypes = [C.c_int, C.c_int, C.c_float, _fp, C.c_int, C.c_float, _fp, C.c_int]
+        L.orc_strsm_rltn.argtypes = [C.c_int, C.c_int, C.c_float, _fp, C.c_int, _fp, C.c_int]
+        L.orc_spotrf_lower.argtypes = [C.c_int, _fp, C.c_int]
+        L.orc_spotrf_lower.restype = C.c_int
+        L.orc_tiled_spotrf_lower.argtypes = [_fpc, C.c_int, C.c_int, C.c_int]
+        L.orc_tiled_spotrf_lower.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+# --------------------------------------------------------------------------- inputs
+def make_spd_like_chameleon(N: int, bump: float = 100.0, uplo: str = "L", seed: int = 12345) -> np.ndarray:
+    """C2:224-252 (called at C2:404 with bump=100, 'L', seed=12345)."""
+    A = np.zeros((N, N), dtype=np.float64, order="F")
+    lib().orc_make_spd_like_chameleon(A, N, N, bump, uplo.encode()[:1], seed)
+    return A
+
+
+def enforce_strict_diag_dominance(A: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """C2:255-264, in place."""
+    N = A.shape[0]
+    lib().orc_enforce_strict_diag_dominance(A, N, A.shape[0], eps)
+    return A
+
+
+def reference_input(N: int) -> np.ndarray:
+    """The matrix the reference client factors (C2:402-405)."""
+    return enforce_strict_diag_dominance(make_spd_like_chameleon(N))
+
+
+def extract_block(A: np.ndarray, B: int, bi: int, bj: int) -> np.ndarray:
+    """C2:280-309: zero-padded B x B column-major tile."""
+    N = A.shape[0]
+    blk = np.zeros((B, B), dtype=np.float64, order="F")
+    lib().orc_extract_block(np.asfortranarray(A), N, N, B, bi, bj, blk)
+    return blk
+
+
+def plgsy_entry(bump: float, seed: int, i: int, j: int) -> float:
+    return lib().orc_plgsy_entry(bump, seed, i, j)
+
+
+def plgsy_tiles(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
+    """Tile-layout matrix (Nb*Nb tiles of B*B doubles, tile order column-major)."""
+    T = np.empty(Nb * Nb * B * B, dtype=np.float64)
+    lib().orc_plgsy_tiles(T, Nb, B, bump, seed)
+    return T
+
+
+# --------------------------------------------------------------------------- tile ops
+def dpotrf(A: np.ndarray) -> tuple[np.ndarray, int]:
+    """CHAMELEON_dpotrf_Tile(ChamLower) on one tile (W2:238). Returns (tile, info)."""
+    A = np.array(A, dtype=np.float64, order="F", copy=True)
+    info = lib().orc_dpotrf_lower(A.shape[0], A, A.shape[0])
+    return A, info
+
+
+def dtrsm(L: np.ndarray, A: np.ndarray, alpha: float = 1.0) -> np.ndarray:
+    """CHAMELEON_dtrsm_Tile(Right, Lower, Trans, NonUnit, alpha, L, A) (W2:323)."""
+    A = np.array(A, dtype=np.float64, order="F", copy=True)
+    L = np.asfortranarray(L, dtype=np.float64)
+    lib().orc_dtrsm_rltn(A.shape[0], A.shape[1], alpha, L, L.shape[0], A, A.shape[0])
+    return A
+
+
+def dsyrk(A: np.ndarray, Cm: np.ndarray, alpha: float = -1.0, beta: float = 1.0) -> np.ndarray:
+    """CHAMELEON_dsyrk_Tile(Lower, NoTrans, alpha, A, beta, C) (W2:416)."""
+    Cm = np.array(Cm, dtype=np.float64, order="F", copy=True)
+    A = np.asfortranarray(A, dtype=np.float64)
+    lib().orc_dsyrk_ln(Cm.shape[0], A.shape[1], alpha, A, A.shape[0], beta, Cm, Cm.shape[0])
+    return Cm
+
+
+def dgemm(Ai: np.ndarray, Aj: np.ndarray, Cm: np.ndarray, alpha: float = -1.0, beta: float = 1.0) -> np.ndarray:
+    """CHAMELEON_dgemm_Tile(NoTrans, Trans, alpha, Ai, Aj, beta, C) (W2:511)."""
+    Cm = np.array(Cm, dtype=np.float64, order="F", copy=True)
+    Ai = np.asfortranarray(Ai, dtype=np.float64)
+    Aj = np.asfortranarray(Aj, dtype=np.float64)
+    lib().orc_dgemm_nt(Cm.shape[0], Cm.shape[1], Ai.shape[1], alpha, Ai, Ai.shape[0], Aj, Aj.shape[0],
+                       beta, Cm, Cm.shape[0])
+    return Cm
+
+
+def spotrf(A):
+    A = np.array(A, dtype=np.float32, order="F", copy=True)
+    info = lib().orc_spotrf_lower(A.shape[0], A, A.shape[0])
+    return A, info
+
+
+def strsm(L, A, alpha=1.0):
+    A = np.array(A, dtype=np.float32, order="F", copy=True)
+    L = np.asfortranarray(L, dtype=np.float32)
+    lib().orc_strsm_rltn(A.shape[0], A.shape[1], alpha, L, L.shape[0], A, A.shape[0])
+    return A
+
+
+def ssyrk(A, Cm, alpha=-1.0, beta=1.0):
+    Cm = np.array(Cm, dtype=np.float32, order="F", copy=True)
+    A = np.asfortranarray(A, dtype=np.float32)
+    lib().orc_ssyrk_ln(Cm.shape[0], A.shape[1], alpha, A, A.shape[0], beta, Cm, Cm.shape[0])
+    return Cm
+
+
+def sgemm(Ai, Aj, Cm, alpha=-1.0, beta=1.0):
+    Cm = np.array(Cm, dtype=np.float32, order="F", copy=True)
+    Ai = np.asfortranarray(Ai, dtype=np.float32)
+    Aj = np.asfortranarray(Aj, dtype=np.float32)
+    lib().orc_sgemm_nt(Cm.shape[0], Cm.shape[1], Ai.shape[1], alpha, Ai, Ai.shape[0], Aj, Aj.shape[0],
+                       beta, Cm, Cm.shape[0])
+    return Cm
+
+
+# --------------------------------------------------------------------------- whole matrix
+def lapack_to_tile(A: np.ndarray, B: int) -> np.ndarray:
+    N = A.shape[0]
+    Nb = (N + B - 1) // B
+    T = np.empty(Nb * Nb * B * B, dtype=np.float64)
+    lib().orc_lapack_to_tile(np.asfortranarray(A), N, N, B, T)
+    return T
+
+
+def tile_to_lapack(T: np.ndarray, N: int, B: int) -> np.ndarray:
+    A = np.zeros((N, N), dtype=np.float64, order="F")
+    lib().orc_tile_to_lapack(np.ascontiguousarray(T), N, N, B, A)
+    return A
+
+
+def tiled_potrf(T: np.ndarray, Nb: int, B: int, nthreads: int = 0) -> int:
+    """The reference wave DAG (C2:506-565) on a tile-layout matrix, in place."""
+    if T.dtype == np.float32:
+        return lib().orc_tiled_spotrf_lower(T, Nb, B, nthreads)
+    return lib().orc_tiled_potrf_lower(T, Nb, B, nthreads)
+
+
+def cholesky_lower(A: np.ndarray, B: int, nthreads: int = 0) -> tuple[np.ndarray, int]:
+    """Factor a LAPACK-layout SPD matrix through the tile DAG; returns (tril(L), info)."""
+    N = A.shape[0]
+    assert N % B == 0
+    T = lapack_to_tile(A, B)
+    info = tiled_potrf(T, N // B, B, nthreads)
+    return np.tril(tile_to_lapack(T, N, B)), info
+
+
+def residual_lower(L: np.ndarray, A: np.ndarray) -> float:
+    """||tril(L) tril(L)^T - A||_F / ||A||_F (the check V6:72-87 intended)."""
+    N = A.shape[0]
+    return lib().orc_residual_lower(np.asfortranarray(L), np.asfortranarray(A), N, N)
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()
+
+
+# --------------------------------------------------------------------------- reference build
+class RefClient:
+    """The reference's own functions (oracle/_ref, built by build_ref.sh)."""
+
+    def __init__(self):
+        path = build_ref()
+        if path is None:
+            raise FileNotFoundError("oracle/_ref/libref_client.so (needs /root/reference)")
+        L = C.CDLL(path)
+        L.ref_make_spd_like_chameleon.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_char, C.c_uint64]
+        L.ref_enforce_strict_diag_dominance.argtypes = [_dp, C.c_int, C.c_int]
+        L.ref_extract_block.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.ref_block_id_from_ij.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.ref_parse_int_str.argtypes = [C.c_char_p, C.c_int]
+        L.ref_load_params.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.L = L
+
+    def reference_input(self, N: int, bump=100.0, uplo="L", seed=12345, dominance=True) -> np.ndarray:
+        A = np.zeros((N, N), dtype=np.float64, order="F")
+        self.L.ref_make_spd_like_chameleon(A, N, N, bump, uplo.encode()[:1], seed)
+        if dominance:
+            self.L.ref_enforce_strict_diag_dominance(A, N, N)
+        return A
+
+    def extract_block(self, A, B, bi, bj):
+        blk = np.zeros((B, B), dtype=np.float64, order="F")
+        self.L.ref_extract_block(np.asfortranarray(A), A.shape[0], A.shape[0], B, bi, bj, blk)
+        return blk
+
+    def block_id_from_ij(self, i, j) -> str:
+        buf = C.create_string_buffer(64)
+        self.L.ref_block_id_from_ij(i, j, buf, 64)
+        return buf.value.decode()
+
+    def parse_int_str(self, s: str, fallback: int) -> int:
+        return self.L.ref_parse_int_str(s.encode(), fallback)
+
+    def load_params(self, argv: list[str]) -> tuple[int, int]:
+        """argv excludes the program name.  Reads CHOLESKY_N/B from this process's env."""
+        full = [b"app"] + [a.encode() for a in argv]
+        arr = (C.c_char_p * len(full))(*full)
+        n, b = C.c_int(), C.c_int()
+        rc = self.L.ref_load_params(len(full), arr, C.byref(n), C.byref(b))
+        if rc:
+            raise ValueError("load_params threw")
+        return n.value, b.value
