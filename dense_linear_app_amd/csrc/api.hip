@@ -1,0 +1,754 @@
+// C ABI of libcholmi.so (include/cholmi.h): process-global context, Chameleon-style
+// descriptors, the synchronous tile operations the reference worker calls
+// (worker_distrib.cpp:238, 323, 416, 511) and the whole-matrix tiled POTRF the
+// reference driver calls (v6_test.c:56), run as the reference client's wave DAG
+// (client_distrib.cpp:506-565) on two HIP streams with one wave of lookahead.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cholmi.h"
+#include "cholmi_internal.h"
+
+using namespace cholmi;
+
+struct chol_desc {
+  int dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q;
+  int mt, nt;        // global tile grid
+  int prow, pcol;    // this process's grid coordinates
+  int lmt, lnt;      // local tile grid
+  size_t esize;
+  void *mat;         // storage as seen by the caller (host or device)
+  bool on_device;    // mat is device memory
+  bool owns;         // library allocated mat
+  // static work list of the trailing updates: local lower tiles sorted by column
+  // descending; entries with column >= j occupy [0, ge[j])
+  int2 *d_list = nullptr;
+  std::vector<int> ge;
+};
+
+namespace {
+
+struct Ctx {
+  bool inited = false;
+  int device = -1;
+  int rank = 0, nranks = 1;
+  hipStream_t s_main = nullptr, s_panel = nullptr;
+  void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k)
+  size_t winv_bytes = 0;
+  int *d_info = nullptr;
+  double *d_acc = nullptr;
+  void *stage[3] = {nullptr, nullptr, nullptr};
+  size_t stage_bytes[3] = {0, 0, 0};
+  std::vector<hipEvent_t> events;
+  bool profiling = false;
+  // stats of the last whole-matrix potrf
+  double total_ms = 0, update_ms = 0, update_flops = 0;
+  int update_launches = 0;
+  std::string last_error;
+};
+Ctx g;
+std::mutex g_mu;
+
+int fail_hip(hipError_t e, const char *what, int line) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s failed at api.hip:%d: %s", what, line, hipGetErrorString(e));
+  g.last_error = buf;
+  return CHOL_ERR_HIP;
+}
+#define HIPCHECK(call)                                        \
+  do {                                                        \
+    hipError_t e_ = (call);                                   \
+    if (e_ != hipSuccess) return fail_hip(e_, #call, __LINE__); \
+  } while (0)
+
+int fail(int code, const char *msg) {
+  g.last_error = msg;
+  return code;
+}
+
+inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+int ensure_stage(int idx, size_t bytes) {
+  if (g.stage_bytes[idx] >= bytes) return 0;
+  if (g.stage[idx]) HIPCHECK(hipFree(g.stage[idx]));
+  g.stage[idx] = nullptr;
+  g.stage_bytes[idx] = 0;
+  HIPCHECK(hipMalloc(&g.stage[idx], bytes));
+  g.stage_bytes[idx] = bytes;
+  return 0;
+}
+
+int ensure_events(size_t n) {
+  while (g.events.size() < n) {
+    hipEvent_t e;
+    HIPCHECK(hipEventCreate(&e));
+    g.events.push_back(e);
+  }
+  return 0;
+}
+
+bool is_device_ptr(const void *p) {
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: not an error for us
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+LocalMat local_mat(const chol_desc *d, void *base) {
+  LocalMat L;
+  L.base = base;
+  L.lmt = d->lmt;
+  L.P = d->p;
+  L.Q = d->q;
+  L.mb = d->mb;
+  L.bsiz = d->bsiz;
+  return L;
+}
+
+template <typename T>
+T *local_tile(const chol_desc *d, void *base, int I, int J) {
+  return reinterpret_cast<T *>(base) + ((long)(I / d->p) + (long)(J / d->q) * d->lmt) * (long)d->bsiz;
+}
+
+bool single_tile_square(const chol_desc *d) {
+  return d->mt == 1 && d->nt == 1 && d->m == d->n && d->mb == d->nb && d->m == d->mb &&
+         d->p == 1 && d->q == 1 && d->i == 0 && d->j == 0;
+}
+
+// ---- staging of one B x B tile (any B, host or device) into a padded device tile
+struct Staged {
+  void *dev = nullptr;  // device tile with ld = ldp
+  int ldp = 0;
+  bool in_place = false;
+};
+
+template <typename T>
+int stage_in(const chol_desc *d, int slot, bool identity_pad, Staged *out) {
+  const int B = d->mb, Bp = roundup(B, MACRO);
+  out->ldp = Bp;
+  if (d->on_device && B == Bp) {
+    out->dev = d->mat;
+    out->in_place = true;
+    return 0;
+  }
+  const size_t bytes = (size_t)Bp * Bp * sizeof(T);
+  int rc = ensure_stage(slot, bytes);
+  if (rc) return rc;
+  T *dst = reinterpret_cast<T *>(g.stage[slot]);
+  if (B != Bp) HIPCHECK(hipMemsetAsync(dst, 0, bytes, g.s_main));
+  HIPCHECK(hipMemcpy2DAsync(dst, (size_t)Bp * sizeof(T), d->mat, (size_t)B * sizeof(T),
+                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.s_main));
+  if (identity_pad) launch_pad_identity<T>(g.s_main, dst, B, Bp);
+  out->dev = dst;
+  out->in_place = false;
+  return 0;
+}
+
+template <typename T>
+int stage_out(const chol_desc *d, const Staged &st) {
+  if (st.in_place) return 0;
+  const int B = d->mb;
+  HIPCHECK(hipMemcpy2DAsync(d->mat, (size_t)B * sizeof(T), st.dev, (size_t)st.ldp * sizeof(T),
+                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.s_main));
+  return 0;
+}
+
+int read_info(int *info) {
+  HIPCHECK(hipMemcpy(info, g.d_info, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- whole-matrix right-looking tiled Cholesky on one GPU --------------------
+template <typename T>
+int potrf_full_device(chol_desc *d, void *base) {
+  const int nt = d->nt, mb = d->mb;
+  const long bsiz = d->bsiz;
+  T *M = reinterpret_cast<T *>(base);
+  T *winv = reinterpret_cast<T *>(g.winv);
+  int rc = ensure_events(2 * (size_t)nt + 4 + (g.profiling ? 4 * (size_t)nt : 0));
+  if (rc) return rc;
+  HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
+  hipEvent_t ev_start = g.events[2 * nt], ev_stop = g.events[2 * nt + 1], ev_join = g.events[2 * nt + 2];
+  HIPCHECK(hipEventRecord(ev_start, g.s_main));
+  HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_start, 0));
+  const LocalMat C = local_mat(d, base);
+  double upd_flops = 0;
+  int upd_launches = 0;
+  for (int k = 0; k < nt; ++k) {
+    hipEvent_t ev_panel = g.events[2 * k], ev_u1 = g.events[2 * k + 1];
+    // panel stream: POTRF(k,k) then TRSM(i,k), i > k  (C2:510-535)
+    T *lkk = M + ((long)k + (long)k * nt) * bsiz;
+    launch_potrf_tile<T>(g.s_panel, lkk, mb, winv, g.d_info, k * mb);
+    launch_trsm_panel<T>(g.s_panel, lkk + bsiz, bsiz, nt - 1 - k, lkk, winv, mb, T(1));
+    HIPCHECK(hipEventRecord(ev_panel, g.s_panel));
+    // main stream: trailing update (C2:540-560); column k+1 first so that the
+    // next panel can start while the rest of the update is still running
+    HIPCHECK(hipStreamWaitEvent(g.s_main, ev_panel, 0));
+    if (k + 1 < nt) {
+      PanelRef pan;
+      memset(&pan, 0, sizeof pan);
+      pan.P = 1;
+      pan.base[0] = M + (long)k * nt * bsiz;
+      pan.first[0] = 0;
+      const int u1_lo = d->ge[k + 2 <= nt ? k + 2 : nt], u1_hi = d->ge[k + 1];
+      hipEvent_t p0 = nullptr, p1 = nullptr, p2 = nullptr;
+      if (g.profiling) {
+        p0 = g.events[2 * nt + 4 + 3 * k];
+        p1 = g.events[2 * nt + 4 + 3 * k + 1];
+        p2 = g.events[2 * nt + 4 + 3 * k + 2];
+        HIPCHECK(hipEventRecord(p0, g.s_main));
+      }
+      launch_trail_update<T>(g.s_main, C, d->d_list, u1_lo, u1_hi - u1_lo, pan);
+      if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
+      HIPCHECK(hipEventRecord(ev_u1, g.s_main));
+      HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
+      if (u1_lo > 0) {
+        launch_trail_update<T>(g.s_main, C, d->d_list, 0, u1_lo, pan);
+        ++upd_launches;
+      }
+      if (g.profiling) HIPCHECK(hipEventRecord(p2, g.s_main));
+      ++upd_launches;
+      // algorithmic flops of this wave's update: GEMM 2B^3 per off-diagonal tile,
+      // SYRK B^3 per diagonal tile
+      const double ntl = (double)(nt - 1 - k);
+      upd_flops += (ntl * (ntl - 1) / 2 * 2.0 + ntl * 1.0) * (double)mb * mb * mb;
+    }
+  }
+  HIPCHECK(hipEventRecord(ev_join, g.s_panel));
+  HIPCHECK(hipStreamWaitEvent(g.s_main, ev_join, 0));
+  HIPCHECK(hipEventRecord(ev_stop, g.s_main));
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  float ms = 0;
+  HIPCHECK(hipEventElapsedTime(&ms, ev_start, ev_stop));
+  g.total_ms = ms;
+  g.update_flops = upd_flops;
+  g.update_launches = upd_launches;
+  g.update_ms = 0;
+  if (g.profiling) {
+    for (int k = 0; k + 1 < nt; ++k) {
+      float a = 0;
+      HIPCHECK(hipEventElapsedTime(&a, g.events[2 * nt + 4 + 3 * k], g.events[2 * nt + 4 + 3 * k + 2]));
+      g.update_ms += a;
+    }
+  }
+  int info = 0;
+  rc = read_info(&info);
+  if (rc) return rc;
+  return info;
+}
+
+int build_worklist(chol_desc *d) {
+  if (d->mt != d->nt) return 0;  // only square tile grids are factored
+  std::vector<int2> list;
+  d->ge.assign(d->nt + 2, 0);
+  for (int J = d->nt - 1; J >= 0; --J) {
+    if (J % d->q == d->pcol)
+      for (int I = J; I < d->mt; ++I)
+        if (I % d->p == d->prow) list.push_back(make_int2(I, J));
+    d->ge[J] = (int)list.size();
+  }
+  d->ge[d->nt] = 0;
+  d->ge[d->nt + 1] = 0;
+  if (!list.empty()) {
+    HIPCHECK(hipMalloc(&d->d_list, list.size() * sizeof(int2)));
+    HIPCHECK(hipMemcpy(d->d_list, list.data(), list.size() * sizeof(int2), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+template <typename T>
+static int potrf_impl(chol_desc *A) {
+  if (single_tile_square(A)) {
+    Staged st;
+    int rc = stage_in<T>(A, 0, /*identity_pad=*/true, &st);
+    if (rc) return rc;
+    HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
+    launch_potrf_tile<T>(g.s_main, reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.winv),
+                         g.d_info, 0);
+    rc = stage_out<T>(A, st);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(g.s_main));
+    int info = 0;
+    rc = read_info(&info);
+    return rc ? rc : info;
+  }
+  if (A->p * A->q != 1)
+    return fail(CHOL_ERR_NOT_SUPPORTED,
+                "potrf_tile on a distributed descriptor: use the chol_wave_* building blocks");
+  if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
+  if ((size_t)(A->mb / MACRO) * MACRO * MACRO * sizeof(T) > g.winv_bytes)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: tile size above 4096");
+  if (A->on_device) return potrf_full_device<T>(A, A->mat);
+  // host-resident tiled matrix: stage the whole matrix through HBM
+  const size_t bytes = (size_t)A->mt * A->nt * A->bsiz * sizeof(T);
+  void *dev = nullptr;
+  if (hipMalloc(&dev, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CHOL_ERR_OUT_OF_MEMORY, "potrf_tile: staging allocation failed");
+  }
+  int rc = 0;
+  hipError_t e = hipMemcpy(dev, A->mat, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = potrf_full_device<T>(A, dev);
+    if (rc >= 0) e = hipMemcpy(A->mat, dev, bytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail_hip(e, "staged potrf copy", __LINE__);
+  return rc;
+}
+
+template <typename T>
+static int trsm_impl(double alpha, chol_desc *L, chol_desc *B) {
+  Staged sl, sb;
+  int rc = stage_in<T>(L, 0, /*identity_pad=*/true, &sl);
+  if (rc) return rc;
+  rc = stage_in<T>(B, 1, false, &sb);
+  if (rc) return rc;
+  T *winv = reinterpret_cast<T *>(g.winv);
+  launch_invert_diag<T>(g.s_main, reinterpret_cast<const T *>(sl.dev), sl.ldp, winv);
+  launch_trsm_panel<T>(g.s_main, reinterpret_cast<T *>(sb.dev), (long)sb.ldp * sb.ldp, 1,
+                       reinterpret_cast<const T *>(sl.dev), winv, sb.ldp, (T)alpha);
+  rc = stage_out<T>(B, sb);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+template <typename T>
+static int gemm_impl(double alpha, chol_desc *A, chol_desc *B, double beta, chol_desc *C, bool lower) {
+  Staged sa, sb, sc;
+  int rc = stage_in<T>(A, 0, false, &sa);
+  if (rc) return rc;
+  if (B == A) {
+    sb = sa;
+  } else {
+    rc = stage_in<T>(B, 1, false, &sb);
+    if (rc) return rc;
+  }
+  rc = stage_in<T>(C, 2, false, &sc);
+  if (rc) return rc;
+  launch_gemm_nt_tile<T>(g.s_main, reinterpret_cast<const T *>(sa.dev), reinterpret_cast<const T *>(sb.dev),
+                         reinterpret_cast<T *>(sc.dev), sc.ldp, (T)alpha, (T)beta, lower);
+  rc = stage_out<T>(C, sc);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *chol_version(void) { return "cholmi 0.1 (gfx950)"; }
+const char *chol_last_error(void) { return g.last_error.c_str(); }
+
+int chol_set_device(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g.inited && device != g.device) return fail(-1, "chol_set_device after chol_init");
+  g.device = device;
+  return 0;
+}
+
+int chol_set_rank(int rank, int nranks) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "chol_set_rank: bad rank");
+  g.rank = rank;
+  g.nranks = nranks;
+  return 0;
+}
+
+int chol_init(int ncpu, int ngpu) {
+  (void)ncpu;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g.inited) return 0;
+  if (ngpu < 1)
+    return fail(CHOL_ERR_NO_GPU, "chol_init: ngpu must be >= 1 (this library has no CPU backend)");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1) {
+    (void)hipGetLastError();
+    return fail(CHOL_ERR_NO_GPU, "chol_init: no HIP device visible");
+  }
+  if (g.device < 0) {
+    const char *lr = getenv("LOCAL_RANK");
+    g.device = lr ? atoi(lr) % count : 0;
+  }
+  if (g.device >= count) return fail(CHOL_ERR_NO_GPU, "chol_init: device index out of range");
+  HIPCHECK(hipSetDevice(g.device));
+  int lo = 0, hi = 0;
+  HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIPCHECK(hipStreamCreateWithPriority(&g.s_main, hipStreamNonBlocking, lo));
+  HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
+  g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
+  HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
+  HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
+  HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
+  HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
+  g.inited = true;
+  return 0;
+}
+
+int chol_finalize(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.inited) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto e : g.events) (void)hipEventDestroy(e);
+  g.events.clear();
+  for (int i = 0; i < 3; ++i) {
+    if (g.stage[i]) (void)hipFree(g.stage[i]);
+    g.stage[i] = nullptr;
+    g.stage_bytes[i] = 0;
+  }
+  (void)hipFree(g.winv);
+  (void)hipFree(g.d_info);
+  (void)hipFree(g.d_acc);
+  (void)hipStreamDestroy(g.s_main);
+  (void)hipStreamDestroy(g.s_panel);
+  g.winv = nullptr;
+  g.d_info = nullptr;
+  g.d_acc = nullptr;
+  g.s_main = g.s_panel = nullptr;
+  g.inited = false;
+  return 0;
+}
+
+int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm,
+                     int ln, int i, int j, int m, int n, int p, int q) {
+  if (!desc) return fail(-1, "desc_create: desc is NULL");
+  *desc = nullptr;
+  if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-3, "desc_create: dtype");
+  if (mb <= 0) return fail(-4, "desc_create: mb");
+  if (nb <= 0) return fail(-5, "desc_create: nb");
+  if (bsiz != mb * nb) return fail(-6, "desc_create: bsiz != mb*nb");
+  if (lm <= 0) return fail(-7, "desc_create: lm");
+  if (ln <= 0) return fail(-8, "desc_create: ln");
+  if (i < 0 || i >= lm) return fail(-9, "desc_create: i");
+  if (j < 0 || j >= ln) return fail(-10, "desc_create: j");
+  if (m <= 0 || i + m > lm) return fail(-11, "desc_create: m");
+  if (n <= 0 || j + n > ln) return fail(-12, "desc_create: n");
+  if (p <= 0 || p > MAXP) return fail(-13, "desc_create: p");
+  if (q <= 0) return fail(-14, "desc_create: q");
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "desc_create before chol_init");
+  if (i != 0 || j != 0 || m != lm || n != ln)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views (i,j,m,n) are not supported");
+  if (p * q != 1 && p * q != g.nranks)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: p*q must equal the number of ranks (chol_set_rank)");
+  chol_desc *d = new chol_desc();
+  d->dtype = dtype; d->mb = mb; d->nb = nb; d->bsiz = bsiz; d->lm = lm; d->ln = ln;
+  d->i = i; d->j = j; d->m = m; d->n = n; d->p = p; d->q = q;
+  d->esize = dtype == CHOL_REAL_DOUBLE ? 8 : 4;
+  d->mt = (lm + mb - 1) / mb;
+  d->nt = (ln + nb - 1) / nb;
+  const int rank = (p * q == 1) ? 0 : g.rank;
+  d->prow = rank / q;
+  d->pcol = rank % q;
+  d->lmt = (d->mt - d->prow + p - 1) / p;
+  d->lnt = (d->nt - d->pcol + q - 1) / q;
+  if (d->lmt < 0) d->lmt = 0;
+  if (d->lnt < 0) d->lnt = 0;
+  const bool multi = d->mt > 1 || d->nt > 1;
+  if (multi && (lm % mb || ln % nb))
+    return delete d, fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: ragged edge tiles are not supported");
+  if (multi && (mb != nb || mb % MACRO))
+    return delete d, fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: tiled matrices need mb == nb, a multiple of 128");
+  if (mat) {
+    d->mat = mat;
+    d->owns = false;
+    d->on_device = is_device_ptr(mat);
+  } else {
+    const size_t bytes = (size_t)std::max(1, d->lmt) * std::max(1, d->lnt) * (size_t)bsiz * d->esize;
+    hipError_t e = hipMalloc(&d->mat, bytes);
+    if (e != hipSuccess) {
+      delete d;
+      (void)hipGetLastError();
+      return fail(CHOL_ERR_OUT_OF_MEMORY, "desc_create: hipMalloc failed");
+    }
+    d->owns = true;
+    d->on_device = true;
+  }
+  if (multi) {
+    int rc = build_worklist(d);
+    if (rc) {
+      if (d->owns) (void)hipFree(d->mat);
+      delete d;
+      return rc;
+    }
+  }
+  *desc = d;
+  return 0;
+}
+
+int chol_desc_destroy(chol_desc_t **desc) {
+  if (!desc || !*desc) return fail(-1, "desc_destroy: NULL");
+  chol_desc *d = *desc;
+  if (d->d_list) (void)hipFree(d->d_list);
+  if (d->owns && d->mat) (void)hipFree(d->mat);
+  delete d;
+  *desc = nullptr;
+  return 0;
+}
+
+void *chol_desc_local_ptr(chol_desc_t *d, size_t *bytes) {
+  if (!d) return nullptr;
+  if (bytes) *bytes = (size_t)d->lmt * d->lnt * (size_t)d->bsiz * d->esize;
+  return d->mat;
+}
+
+int chol_desc_local_tiles(chol_desc_t *d, int *lmt, int *lnt) {
+  if (!d) return fail(-1, "NULL desc");
+  if (lmt) *lmt = d->lmt;
+  if (lnt) *lnt = d->lnt;
+  return 0;
+}
+
+// ---------------------------------------------------------------- POTRF
+int chol_potrf_tile(int uplo, chol_desc_t *A) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_tile before chol_init");
+  if (uplo != CHOL_LOWER)
+    return fail(uplo == CHOL_UPPER ? CHOL_ERR_NOT_SUPPORTED : -1, "potrf_tile: only ChamLower");
+  if (!A) return fail(-2, "potrf_tile: NULL descriptor");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
+}
+
+// ---------------------------------------------------------------- TRSM
+int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_desc_t *A,
+                   chol_desc_t *B) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "trsm_tile before chol_init");
+  if (side != CHOL_LEFT && side != CHOL_RIGHT) return fail(-1, "trsm_tile: side");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-2, "trsm_tile: uplo");
+  if (trans != CHOL_NOTRANS && trans != CHOL_TRANS) return fail(-3, "trsm_tile: trans");
+  if (diag != CHOL_NONUNIT && diag != CHOL_UNIT) return fail(-4, "trsm_tile: diag");
+  if (!A) return fail(-6, "trsm_tile: A is NULL");
+  if (!B) return fail(-7, "trsm_tile: B is NULL");
+  if (side != CHOL_RIGHT || uplo != CHOL_LOWER || trans != CHOL_TRANS || diag != CHOL_NONUNIT)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "trsm_tile: only (Right, Lower, Trans, NonUnit)");
+  if (!single_tile_square(A) || !single_tile_square(B) || A->mb != B->mb || A->dtype != B->dtype)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "trsm_tile: needs two 1-tile descriptors of equal size and type");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return A->dtype == CHOL_REAL_DOUBLE ? trsm_impl<double>(alpha, A, B) : trsm_impl<float>(alpha, A, B);
+}
+
+// ---------------------------------------------------------------- SYRK / GEMM
+int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *C) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "syrk_tile before chol_init");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "syrk_tile: uplo");
+  if (trans != CHOL_NOTRANS && trans != CHOL_TRANS) return fail(-2, "syrk_tile: trans");
+  if (!A) return fail(-4, "syrk_tile: A is NULL");
+  if (!C) return fail(-6, "syrk_tile: C is NULL");
+  if (uplo != CHOL_LOWER || trans != CHOL_NOTRANS)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "syrk_tile: only (Lower, NoTrans)");
+  if (!single_tile_square(A) || !single_tile_square(C) || A->mb != C->mb || A->dtype != C->dtype)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "syrk_tile: needs two 1-tile descriptors of equal size and type");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return A->dtype == CHOL_REAL_DOUBLE ? gemm_impl<double>(alpha, A, A, beta, C, true)
+                                      : gemm_impl<float>(alpha, A, A, beta, C, true);
+}
+
+int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
+                   double beta, chol_desc_t *C) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "gemm_tile before chol_init");
+  if (transA != CHOL_NOTRANS && transA != CHOL_TRANS) return fail(-1, "gemm_tile: transA");
+  if (transB != CHOL_NOTRANS && transB != CHOL_TRANS) return fail(-2, "gemm_tile: transB");
+  if (!A) return fail(-4, "gemm_tile: A is NULL");
+  if (!B) return fail(-5, "gemm_tile: B is NULL");
+  if (!C) return fail(-7, "gemm_tile: C is NULL");
+  if (transA != CHOL_NOTRANS || transB != CHOL_TRANS)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "gemm_tile: only (NoTrans, Trans)");
+  if (!single_tile_square(A) || !single_tile_square(B) || !single_tile_square(C) || A->mb != C->mb ||
+      B->mb != C->mb || A->dtype != C->dtype || B->dtype != C->dtype)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "gemm_tile: needs three 1-tile descriptors of equal size and type");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return A->dtype == CHOL_REAL_DOUBLE ? gemm_impl<double>(alpha, A, B, beta, C, false)
+                                      : gemm_impl<float>(alpha, A, B, beta, C, false);
+}
+
+// ---------------------------------------------------------------- generator / layout / residual
+int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "plgsy_tile before chol_init");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-2, "plgsy_tile: uplo");
+  if (!A) return fail(-3, "plgsy_tile: NULL descriptor");
+  if (!A->on_device) return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: descriptor must be device-resident");
+  if (A->mt == 1 && A->nt == 1 && (A->m != A->mb || A->n != A->nb))
+    return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: partial single tile");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const LocalMat L = local_mat(A, A->mat);
+  if (A->dtype == CHOL_REAL_DOUBLE)
+    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed);
+  else
+    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed);
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
+  if (!d || !host_tile) return fail(-1, "tile_upload: NULL");
+  if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
+    return fail(-2, "tile_upload: tile not owned by this process");
+  char *dst = reinterpret_cast<char *>(d->mat) +
+              ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsiz * d->esize;
+  HIPCHECK(hipMemcpy(dst, host_tile, (size_t)d->bsiz * d->esize, hipMemcpyDefault));
+  return 0;
+}
+
+int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
+  if (!d || !host_tile) return fail(-1, "tile_download: NULL");
+  if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
+    return fail(-2, "tile_download: tile not owned by this process");
+  const char *src = reinterpret_cast<const char *>(d->mat) +
+                    ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsiz * d->esize;
+  HIPCHECK(hipMemcpy(host_tile, src, (size_t)d->bsiz * d->esize, hipMemcpyDefault));
+  return 0;
+}
+
+int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
+  if (!A || !d) return fail(-1, "lapack_to_tile: NULL");
+  if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "lapack_to_tile: single-process descriptors only");
+  if (lda < d->lm) return fail(-2, "lapack_to_tile: lda");
+  for (int J = 0; J < d->nt; ++J)
+    for (int I = 0; I < d->mt; ++I) {
+      char *dst = reinterpret_cast<char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsiz * d->esize;
+      const char *src = reinterpret_cast<const char *>(A) + ((size_t)I * d->mb + (size_t)J * d->nb * lda) * d->esize;
+      HIPCHECK(hipMemcpy2D(dst, (size_t)d->mb * d->esize, src, (size_t)lda * d->esize,
+                           (size_t)d->mb * d->esize, d->nb, hipMemcpyDefault));
+    }
+  return 0;
+}
+
+int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
+  if (!A || !d) return fail(-1, "tile_to_lapack: NULL");
+  if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_to_lapack: single-process descriptors only");
+  if (lda < d->lm) return fail(-3, "tile_to_lapack: lda");
+  for (int J = 0; J < d->nt; ++J)
+    for (int I = 0; I < d->mt; ++I) {
+      const char *src = reinterpret_cast<const char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsiz * d->esize;
+      char *dst = reinterpret_cast<char *>(A) + ((size_t)I * d->mb + (size_t)J * d->nb * lda) * d->esize;
+      HIPCHECK(hipMemcpy2D(dst, (size_t)lda * d->esize, src, (size_t)d->mb * d->esize,
+                           (size_t)d->mb * d->esize, d->nb, hipMemcpyDefault));
+    }
+  return 0;
+}
+
+int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "residual before chol_init");
+  if (!L || !rel) return fail(-1, "residual: NULL");
+  if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mb % MACRO)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "residual: single-process device-resident square tiled matrix only");
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIPCHECK(hipMemsetAsync(g.d_acc, 0, 2 * sizeof(double), g.s_main));
+  if (L->dtype == CHOL_REAL_DOUBLE)
+    launch_residual<double>(g.s_main, reinterpret_cast<const double *>(L->mat), L->nt, L->mb, bump, seed, g.d_acc);
+  else
+    launch_residual<float>(g.s_main, reinterpret_cast<const float *>(L->mat), L->nt, L->mb, bump, seed, g.d_acc);
+  double h[2];
+  HIPCHECK(hipMemcpyAsync(h, g.d_acc, sizeof h, hipMemcpyDeviceToHost, g.s_main));
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  *rel = sqrt(h[0]) / sqrt(h[1]);
+  return 0;
+}
+
+// ---------------------------------------------------------------- instrumentation
+int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launches, double *update_flops) {
+  if (total_ms) *total_ms = g.total_ms;
+  if (update_ms) *update_ms = g.update_ms;
+  if (update_launches) *update_launches = g.update_launches;
+  if (update_flops) *update_flops = g.update_flops;
+  return 0;
+}
+
+int chol_set_profiling(int on) {
+  g.profiling = on != 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------- distributed building blocks
+int chol_get_info(int *info) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "get_info before chol_init");
+  HIPCHECK(hipDeviceSynchronize());
+  return read_info(info);
+}
+
+int chol_reset_info(void) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "reset_info before chol_init");
+  HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
+  return 0;
+}
+
+int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_potrf before chol_init");
+  if (!d || !lkk) return fail(-1, "wave_potrf: NULL");
+  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  if (d->dtype == CHOL_REAL_DOUBLE)
+    launch_potrf_tile<double>(s, (double *)lkk, d->mb, (double *)g.winv, g.d_info, k * d->mb);
+  else
+    launch_potrf_tile<float>(s, (float *)lkk, d->mb, (float *)g.winv, g.d_info, k * d->mb);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_invert_diag before chol_init");
+  if (!d || !lkk) return fail(-1, "wave_invert_diag: NULL");
+  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  if (d->dtype == CHOL_REAL_DOUBLE)
+    launch_invert_diag<double>(s, (const double *)lkk, d->mb, (double *)g.winv);
+  else
+    launch_invert_diag<float>(s, (const float *)lkk, d->mb, (float *)g.winv);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_trsm before chol_init");
+  if (!d || !lkk) return fail(-1, "wave_trsm: NULL");
+  if (k % d->q != d->pcol) return 0;  // this process column holds no tile of panel k
+  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  const int il0 = (k + d->p - d->prow) / d->p;  // first local row with global index > k
+  const int cnt = d->lmt - il0;
+  if (cnt <= 0) return 0;
+  const size_t off = ((size_t)il0 + (size_t)(k / d->q) * d->lmt) * (size_t)d->bsiz;
+  if (d->dtype == CHOL_REAL_DOUBLE)
+    launch_trsm_panel<double>(s, (double *)d->mat + off, d->bsiz, cnt, (const double *)lkk,
+                              (const double *)g.winv, d->mb, 1.0);
+  else
+    launch_trsm_panel<float>(s, (float *)d->mat + off, d->bsiz, cnt, (const float *)lkk,
+                             (const float *)g.winv, d->mb, 1.0f);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const *panel_base,
+                     const int *panel_first, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update before chol_init");
+  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update: NULL");
+  if (jlo <= k) jlo = k + 1;
+  if (jhi > d->nt) jhi = d->nt;
+  if (jlo >= jhi) return 0;
+  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  PanelRef pan;
+  memset(&pan, 0, sizeof pan);
+  pan.P = d->p;
+  for (int r = 0; r < d->p; ++r) {
+    pan.base[r] = panel_base[r];
+    pan.first[r] = panel_first[r];
+  }
+  const int lo = d->ge[jhi], hi = d->ge[jlo];
+  const LocalMat C = local_mat(d, d->mat);
+  if (d->dtype == CHOL_REAL_DOUBLE)
+    launch_trail_update<double>(s, C, d->d_list, lo, hi - lo, pan);
+  else
+    launch_trail_update<float>(s, C, d->d_list, lo, hi - lo, pan);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

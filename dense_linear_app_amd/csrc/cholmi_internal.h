@@ -1,0 +1,74 @@
+// Internal declarations shared by the kernel and API translation units of
+// libcholmi.so.  Not part of the ABI (that is include/cholmi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+namespace cholmi {
+
+constexpr int MACRO = 128;  // macro-tile edge: one workgroup's C block, and the
+                            // diagonal-block size of the in-tile POTRF/TRSM
+constexpr int MAXP = 8;     // max process-grid rows a panel reference can address
+
+// Where the panel tiles L(i,k) of the current wave live.  Tile i is at
+// base[i % P] + (i / P - first[i % P]) * bsiz  (elements).  Single GPU: P = 1,
+// base[0] = column k of the matrix itself, first[0] = 0 (no copy).
+struct PanelRef {
+  const void *base[MAXP];
+  int first[MAXP];
+  int P;
+};
+
+// This process's part of a 2D block-cyclic tile matrix.
+struct LocalMat {
+  void *base;
+  int lmt;   // local tile rows (leading dimension of the local tile grid)
+  int P, Q;  // process grid
+  int mb;    // tile edge (= ld inside a tile)
+  long bsiz; // elements per tile
+};
+
+// ---- launchers (kernels.hip) ---------------------------------------------
+// C(i,j) -= L(i,k) L(j,k)^T for the `ntiles` (i,j) pairs in d_list[off .. off+ntiles)
+template <typename T>
+void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int ntiles,
+                         const PanelRef &pan);
+
+// In-tile blocked POTRF of one mb x mb tile (device pointer, ld = mb).  Writes the
+// inverses of the MACRO x MACRO diagonal blocks of L to winv (mb/MACRO blocks of
+// MACRO*MACRO elements, ld = MACRO).  info: device int, set to info_base + j (1-based)
+// at the first non-positive pivot (first writer wins).
+template <typename T>
+void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base);
+
+// winv from an already factored tile
+template <typename T>
+void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv);
+
+// tiles[t] := alpha * tiles[t] * L^{-T}, t < ntiles, tiles contiguous (stride bsiz)
+template <typename T>
+void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv,
+                       int mb, T alpha);
+
+// generic 1-tile C := alpha A B^T + beta C (lower_only: SYRK semantics)
+template <typename T>
+void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T alpha, T beta,
+                         bool lower_only);
+
+template <typename T>
+void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
+                  unsigned long long seed);
+
+// accumulates sum((LL^T - A)^2) and sum(A^2) over the lower triangle (strict part
+// counted twice) into acc[0], acc[1] (device doubles).  Single process only.
+template <typename T>
+void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
+                     unsigned long long seed, double *d_acc);
+
+// pad helpers for the staged 1-tile path: dst is ldp x ldp (zeroed), identity on
+// the padded part of the diagonal when `unit_pad`.
+template <typename T>
+void launch_pad_identity(hipStream_t s, T *dst, int n, int ldp);
+
+}  // namespace cholmi

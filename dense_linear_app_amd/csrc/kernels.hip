@@ -1,0 +1,527 @@
+// gfx950 (CDNA4) kernels of libcholmi.so: the four tile operations of the
+// reference's Cholesky worker (worker_distrib.cpp:238 POTRF, :323 TRSM, :416 SYRK,
+// :511 GEMM) plus the on-device generator / residual of the driver path
+// (v6_test.c:46, 72-87).  Written for 64-wide wavefronts and the fp64 / fp32
+// 16x16x4 MFMA; no other target is supported.
+//
+// Common structure ("NT core"): one 256-thread workgroup (4 waves, 2 x 2) owns a
+// 128 x 128 block of C and computes  acc = A(128 x K) * B(128 x K)^T  with both
+// operands column-major (rows contiguous), staged through LDS in K-slices of 16:
+//   - global -> registers: 16-byte loads, one wave instruction = 1 KiB contiguous
+//     (a whole 128-row column of the slice): fully coalesced;
+//   - registers -> LDS image [k][row], row stride 144 elements so the four
+//     16-lane groups of a fragment read land on disjoint bank halves;
+//   - LDS -> MFMA fragments: lane l reads X[k0 + (l >> 4)][r0 + (l & 15)], which is
+//     exactly the 16x16x4 operand layout for both the A and the B operand;
+//   - the operands are passed swapped (B-fragment as MFMA "A"), so each lane's
+//     accumulator holds consecutive ROWS of C in consecutive lanes: the C
+//     read-modify-write is 128-byte contiguous per 16 lanes (col-major C).
+// Double-buffered LDS, one barrier per K-slice; 2 workgroups per CU
+// (<= 256 VGPR, 72 KiB LDS each) hide the C epilogue behind the other
+// workgroup's MFMA stream.
+#include "cholmi_internal.h"
+
+namespace cholmi {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<double> {
+  using acc_t = d4_t;
+  using vec_t = d2_t;
+  static constexpr int EPV = 2;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // row of accumulator register `reg` held by `lane` (f64 16x16x4 C/D map)
+  static __device__ __forceinline__ int drow(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Tr<float> {
+  using acc_t = f4_t;
+  using vec_t = f4_t;
+  static constexpr int EPV = 4;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+constexpr int BK = 16;
+constexpr int LROW = MACRO + 16;
+
+template <typename T>
+struct Smem {
+  T a[2][BK][LROW];
+  T b[2][BK][LROW];
+};
+
+template <typename T>
+using Acc = typename Tr<T>::acc_t[4][4];
+
+template <typename T>
+__device__ __forceinline__ void acc_zero(Acc<T> &acc) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+}
+
+// acc += A(128 x K) * B(128 x K)^T.  MASKA / MASKB: treat the operand as the lower
+// triangle of a square tile whose row `amask + r` only has columns k <= amask + r
+// (used by the residual kernel to read tril(L(j,j))).
+template <typename T, bool MASKA, bool MASKB>
+__device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const T *__restrict__ B,
+                                         int ldb, int K, Acc<T> &acc, Smem<T> &sm, int amask,
+                                         int bmask) {
+  using vec_t = typename Tr<T>::vec_t;
+  constexpr int EPV = Tr<T>::EPV;
+  constexpr int TPC = MACRO / EPV;  // threads per k-column
+  constexpr int CPP = 256 / TPC;    // k-columns per pass
+  constexpr int NP = BK / CPP;      // passes per slice
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+  const int lrow = (t % TPC) * EPV, lcol = t / TPC;
+  vec_t ra[NP], rb[NP];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int kk = k0 + p * CPP + lcol;
+      ra[p] = *reinterpret_cast<const vec_t *>(A + lrow + (size_t)kk * lda);
+      rb[p] = *reinterpret_cast<const vec_t *>(B + lrow + (size_t)kk * ldb);
+      if (MASKA) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e)
+          if (kk > amask + lrow + e) ra[p][e] = T(0);
+      }
+      if (MASKB) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e)
+          if (kk > bmask + lrow + e) rb[p][e] = T(0);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<vec_t *>(&sm.a[buf][p * CPP + lcol][lrow]) = ra[p];
+      *reinterpret_cast<vec_t *>(&sm.b[buf][p * CPP + lcol][lrow]) = rb[p];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      T af[4], bf[4];
+      const int kk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = sm.a[cur][kk][wr * 64 + a * 16 + (lane & 15)];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = sm.b[cur][kk][wc * 64 + b * 16 + (lane & 15)];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = Tr<T>::mfma(bf[b], af[a], acc[a][b]);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+}
+
+// C(128x128 block) := alpha*acc + beta*C ; lower: keep only (moff + m >= noff + n)
+template <typename T>
+__device__ __forceinline__ void nt_epilogue(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
+                                            T beta, bool lower, int moff, int noff) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int m = wr * 64 + a * 16 + (lane & 15);
+        if (lower && (moff + m < noff + n)) continue;
+        T *p = C + m + (size_t)n * ldc;
+        T v = alpha * acc[a][b][r];
+        if (beta != T(0)) v += beta * (*p);
+        *p = v;
+      }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ const T *panel_tile(const PanelRef &pan, int i, long bsiz) {
+  const int p = i % pan.P;
+  return reinterpret_cast<const T *>(pan.base[p]) + (long)(i / pan.P - pan.first[p]) * bsiz;
+}
+
+// ------------------------------------------------------------------------------
+// Trailing update of one wave (GEMM + SYRK tasks of C2:540-560 fused in one launch):
+//   C(i,j) -= L(i,k) L(j,k)^T for every (i,j) in list[0..ntiles), diagonal tiles
+//   lower-triangle only (dsyrk Lower semantics, W2:416: strict upper untouched).
+// blockIdx -> (tile, macro block) is XCD-aware: blocks with equal blockIdx % 8
+// share an XCD (and its L2); all macro blocks of one tile, and G consecutive tiles
+// of the list, are dealt to the same XCD so the two panel tiles they stream are
+// fetched from HBM once per XCD.
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
+                                                         int ntiles, PanelRef pan, int nbm, int G) {
+  __shared__ Smem<T> sm;
+  const int MT = nbm * nbm;
+  const int b = blockIdx.x, x = b & 7, s = b >> 3;
+  const int sg = s / MT, macro = s - sg * MT;
+  const int t = (sg / G) * (8 * G) + x * G + (sg % G);
+  if (t >= ntiles) return;
+  const int2 ij = list[t];
+  const int mi = macro % nbm, mj = macro / nbm;
+  const bool diag = (ij.x == ij.y);
+  if (diag && mi < mj) return;
+  const T *Ap = panel_tile<T>(pan, ij.x, C.bsiz) + mi * MACRO;
+  const T *Bp = panel_tile<T>(pan, ij.y, C.bsiz) + mj * MACRO;
+  T *Cp = reinterpret_cast<T *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
+          mi * MACRO + (long)mj * MACRO * C.mb;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop<T, false, false>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, 0, 0);
+  nt_epilogue<T>(Cp, C.mb, acc, T(-1), T(1), diag && mi == mj, 0, 0);
+}
+
+// X[:, s] := alpha * A[:, s] * Winv_s^T, in place, for row blocks r >= r0 of `ntiles`
+// contiguous tiles.  (TRSM by multiplication with the inverted 128x128 diagonal block.)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int mb, int nbm, int r0,
+                                                        int s, const T *__restrict__ winv, T alpha) {
+  __shared__ Smem<T> sm;
+  const int nr = nbm - r0;
+  const int tix = blockIdx.x / nr, r = r0 + blockIdx.x % nr;
+  T *Ap = tiles + (long)tix * bsiz + r * MACRO + (long)s * MACRO * mb;
+  const T *Bp = winv + (long)s * MACRO * MACRO;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop<T, false, false>(Ap, mb, Bp, MACRO, MACRO, acc, sm, 0, 0);
+  nt_epilogue<T>(Ap, mb, acc, alpha, T(0), false, 0, 0);
+}
+
+// A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, int mb, int nbm, int s,
+                                                         const T *__restrict__ lkk, T beta) {
+  __shared__ Smem<T> sm;
+  const int nc = nbm - 1 - s;
+  int b = blockIdx.x;
+  const int c = s + 1 + b % nc;
+  b /= nc;
+  const int r = b % nbm, tix = b / nbm;
+  T *tile = tiles + (long)tix * bsiz;
+  const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
+  const T *Bp = lkk + c * MACRO + (long)s * MACRO * mb;
+  T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop<T, false, false>(Ap, mb, Bp, mb, MACRO, acc, sm, 0, 0);
+  nt_epilogue<T>(Cp, mb, acc, T(-1), beta, false, 0, 0);
+}
+
+// in-tile trailing update of the blocked POTRF: C[r,c] -= X[r,s] X[c,s]^T, r >= c > s
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s) {
+  __shared__ Smem<T> sm;
+  const int r = s + 1 + blockIdx.x, c = s + 1 + blockIdx.y;
+  if (c > r) return;
+  const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
+  const T *Bp = tile + c * MACRO + (long)s * MACRO * mb;
+  T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop<T, false, false>(Ap, mb, Bp, mb, MACRO, acc, sm, 0, 0);
+  nt_epilogue<T>(Cp, mb, acc, T(-1), T(1), r == c, 0, 0);
+}
+
+// generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A,
+                                                         const T *__restrict__ B, T *C, int mb,
+                                                         int nbm, T alpha, T beta, int lower) {
+  __shared__ Smem<T> sm;
+  const int mi = blockIdx.x, mj = blockIdx.y;
+  if (lower && mi < mj) return;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop<T, false, false>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm, 0, 0);
+  nt_epilogue<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta,
+                 lower && mi == mj, 0, 0);
+}
+
+// ------------------------------------------------------------------------------
+// 128 x 128 diagonal block: unblocked lower Cholesky in LDS (right-looking, one
+// column per step) followed by the in-place inverse of the triangular factor
+// (LAPACK dtrti2 'L' order), one workgroup.  factor = 0: only invert an already
+// factored block.  Strict upper triangle of A is never read or written.
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
+                                                    int info_base, int factor) {
+  constexpr int n = MACRO, LS = MACRO + 1;
+  __shared__ T S[n * LS];
+  __shared__ T col[n];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int i = idx & (n - 1), j = idx >> 7;
+    S[i + j * LS] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
+  }
+  __syncthreads();
+  if (factor) {
+    const int i = t & (n - 1), half = t >> 7;
+    for (int j = 0; j < n; ++j) {
+      T d = S[j + j * LS];
+      if (!(d > T(0))) {  // non-positive or NaN pivot: LAPACK info = j (1-based)
+        if (t == 0) atomicCAS(info, 0, info_base + j + 1);
+        return;
+      }
+      d = sqrt(d);
+      const T rinv = T(1) / d;
+      __syncthreads();  // everyone has read the pivot
+      if (t == j) S[j + j * LS] = d;
+      if (t > j && t < n) S[t + j * LS] *= rinv;
+      __syncthreads();
+      if (i > j) {
+        const T lij = S[i + j * LS];
+        for (int c = j + 1 + half; c <= i; c += 2) S[i + c * LS] -= lij * S[c + j * LS];
+      }
+      __syncthreads();
+    }
+    for (int idx = t; idx < n * n; idx += 256) {
+      const int i2 = idx & (n - 1), j2 = idx >> 7;
+      if (i2 >= j2) A[i2 + (size_t)j2 * ld] = S[i2 + j2 * LS];
+    }
+  }
+  // in-place inverse of the lower-triangular factor
+  for (int j = n - 1; j >= 0; --j) {
+    const T ajj = T(1) / S[j + j * LS];
+    if (t > j && t < n) col[t] = S[t + j * LS];
+    __syncthreads();
+    if (t > j && t < n) {
+      T sum = T(0);
+      for (int k = j + 1; k <= t; ++k) sum += S[t + k * LS] * col[k];
+      S[t + j * LS] = -ajj * sum;
+    }
+    if (t == j) S[j + j * LS] = ajj;
+    __syncthreads();
+  }
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int i2 = idx & (n - 1), j2 = idx >> 7;
+    winv[idx] = (i2 >= j2) ? S[i2 + j2 * LS] : T(0);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// plgsy: symmetric pseudo-random matrix, counter-based (must match
+// oracle/chol_oracle.c:orc_plgsy_entry bit for bit).
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double plgsy_entry(double bump, uint64_t seed, long i, long j) {
+  const uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+  const uint64_t h = splitmix64(splitmix64(seed ^ (hi << 32 | lo)) + lo);
+  const double v = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  return (i == j) ? v + bump : v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_plgsy(LocalMat A, int lnt, int prow, int pcol, double bump,
+                                               unsigned long long seed) {
+  const long per_tile = A.bsiz;
+  const long total = (long)A.lmt * lnt * per_tile;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long tl = idx / per_tile, e = idx - tl * per_tile;
+    const int il = (int)(tl % A.lmt), jl = (int)(tl / A.lmt);
+    const long gi = ((long)il * A.P + prow) * A.mb + e % A.mb;
+    const long gj = ((long)jl * A.Q + pcol) * A.mb + e / A.mb;
+    reinterpret_cast<T *>(A.base)[idx] = (T)plgsy_entry(bump, seed, gi, gj);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// Residual: for every 128x128 block on or below the diagonal,
+//   R = sum_{kt <= j} tril?(L(i,kt)) tril?(L(j,kt))^T - A(i,j),  A regenerated.
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int Nb, int mb, int nbm,
+                                                     double bump, unsigned long long seed,
+                                                     double *acc_out) {
+  __shared__ Smem<T> sm;
+  __shared__ double red[2][4];
+  const int MT = nbm * nbm;
+  const int tix = blockIdx.x / MT, macro = blockIdx.x % MT;
+  // tix -> (i >= j), row-major over the lower triangle
+  int i = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while ((long)i * (i + 1) / 2 > tix) --i;
+  while ((long)(i + 1) * (i + 2) / 2 <= tix) ++i;
+  const int j = tix - i * (i + 1) / 2;
+  const int mi = macro % nbm, mj = macro / nbm;
+  if (i == j && mi < mj) return;
+  const long bsiz = (long)mb * mb;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  for (int kt = 0; kt <= j; ++kt) {
+    const T *Ap = L + ((long)i + (long)kt * Nb) * bsiz + mi * MACRO;
+    const T *Bp = L + ((long)j + (long)kt * Nb) * bsiz + mj * MACRO;
+    if (kt < j)
+      nt_kloop<T, false, false>(Ap, mb, Bp, mb, mb, acc, sm, 0, 0);
+    else if (i != j)
+      nt_kloop<T, false, true>(Ap, mb, Bp, mb, mb, acc, sm, 0, mj * MACRO);
+    else
+      nt_kloop<T, true, true>(Ap, mb, Bp, mb, mb, acc, sm, mi * MACRO, mj * MACRO);
+  }
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+  double num = 0.0, den = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long gi = (long)i * mb + mi * MACRO + wr * 64 + a * 16 + (lane & 15);
+        const long gj = (long)j * mb + mj * MACRO + wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+        if (gi < gj) continue;
+        const double aij = (double)(T)plgsy_entry(bump, seed, gi, gj);
+        const double d = (double)acc[a][b][r] - aij;
+        const double wgt = (gi == gj) ? 1.0 : 2.0;
+        num += wgt * d * d;
+        den += wgt * aij * aij;
+      }
+  for (int o = 32; o > 0; o >>= 1) {
+    num += __shfl_down(num, o, 64);
+    den += __shfl_down(den, o, 64);
+  }
+  if (lane == 0) {
+    red[0][w] = num;
+    red[1][w] = den;
+  }
+  __syncthreads();
+  if (t == 0) {
+    atomicAdd(&acc_out[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&acc_out[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+template <typename T>
+__global__ void k_pad_identity(T *dst, int n, int ldp) {
+  const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ldp) dst[i + (size_t)i * ldp] = T(1);
+}
+
+// ------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------
+template <typename T>
+void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int ntiles,
+                         const PanelRef &pan) {
+  if (ntiles <= 0) return;
+  const int nbm = C.mb / MACRO, MT = nbm * nbm;
+  int G = 64 / MT;
+  if (G < 1) G = 1;
+  const int ngroups = (ntiles + 8 * G - 1) / (8 * G);
+  const long blocks = (long)ngroups * 8 * G * MT;
+  k_trail_update<T><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
+}
+
+template <typename T>
+void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base) {
+  const int nbm = mb / MACRO;
+  for (int st = 0; st < nbm; ++st) {
+    k_potrf_diag<T><<<1, 256, 0, s>>>(tile + (long)st * MACRO * (mb + 1), mb,
+                                      winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1);
+    const int nr = nbm - 1 - st;
+    if (nr > 0) {
+      k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1));
+      k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st);
+    }
+  }
+}
+
+template <typename T>
+void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
+  const int nbm = mb / MACRO;
+  for (int st = 0; st < nbm; ++st)
+    k_potrf_diag<T><<<1, 256, 0, s>>>(const_cast<T *>(tile) + (long)st * MACRO * (mb + 1), mb,
+                                      winv + (long)st * MACRO * MACRO, nullptr, 0, 0);
+}
+
+template <typename T>
+void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv,
+                       int mb, T alpha) {
+  if (ntiles <= 0) return;
+  const int nbm = mb / MACRO;
+  for (int st = 0; st < nbm; ++st) {
+    // alpha is applied once to every column block: in the solve of block 0 and as
+    // the beta of the first update of blocks > 0
+    k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv,
+                                                  st == 0 ? alpha : T(1));
+    const int nc = nbm - 1 - st;
+    if (nc > 0)
+      k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk,
+                                                          st == 0 ? alpha : T(1));
+  }
+}
+
+template <typename T>
+void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T alpha, T beta,
+                         bool lower_only) {
+  const int nbm = mb / MACRO;
+  k_gemm_nt_tile<T><<<dim3(nbm, nbm), 256, 0, s>>>(A, B, C, mb, nbm, alpha, beta, lower_only ? 1 : 0);
+}
+
+template <typename T>
+void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
+                  unsigned long long seed) {
+  k_plgsy<T><<<4096, 256, 0, s>>>(A, lnt, prow, pcol, bump, seed);
+}
+
+template <typename T>
+void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
+                     unsigned long long seed, double *d_acc) {
+  const int nbm = mb / MACRO;
+  const long ntile = (long)Nb * (Nb + 1) / 2;
+  k_residual<T><<<dim3((unsigned)(ntile * nbm * nbm)), 256, 0, s>>>(Lbase, Nb, mb, nbm, bump, seed, d_acc);
+}
+
+template <typename T>
+void launch_pad_identity(hipStream_t s, T *dst, int n, int ldp) {
+  if (ldp > n) k_pad_identity<T><<<(ldp - n + 127) / 128, 128, 0, s>>>(dst, n, ldp);
+}
+
+#define INSTANTIATE(T)                                                                              \
+  template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int,       \
+                                       const PanelRef &);                                           \
+  template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int);                       \
+  template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
+  template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
+  template void launch_gemm_nt_tile<T>(hipStream_t, const T *, const T *, T *, int, T, T, bool);    \
+  template void launch_plgsy<T>(hipStream_t, const LocalMat &, int, int, int, double,               \
+                                unsigned long long);                                                \
+  template void launch_residual<T>(hipStream_t, const T *, int, int, double, unsigned long long,    \
+                                   double *);                                                       \
+  template void launch_pad_identity<T>(hipStream_t, T *, int, int);
+INSTANTIATE(double)
+INSTANTIATE(float)
+
+}  // namespace cholmi

@@ -1,0 +1,171 @@
+/*
+ * cholmi.h -- C ABI of libcholmi.so: the MI355X (gfx950) replacement for the
+ * Chameleon calls on the reference's tiled-Cholesky path.
+ *
+ * Every entry point is `extern "C"`, takes plain ints / doubles / pointers, and
+ * replaces exactly one call the reference makes into libchameleon.so.  Citations
+ * are relative to /root/reference/ :
+ *   W2 = cholesky_armonik/w_c_cons_v2/worker_construction2/src/worker_distrib.cpp
+ *   C2 = cholesky_armonik/w_c_cons_v2/client_construction2/client/src/client_distrib.cpp
+ *   V6 = Cholesky_chameleon_VM/cho/docker_installation_and_bench_files/v6_test.c
+ *
+ * Conventions
+ *   - All tile operations are synchronous at this boundary (they return after
+ *     the result is visible in the descriptor's memory), as Chameleon's
+ *     non-_Async API is.
+ *   - Return value: 0 on success; > 0 a LAPACK-style `info` (POTRF: 1-based
+ *     global index of the first non-positive pivot); < 0 the negated 1-based
+ *     position of the first invalid argument; <= -100 a runtime failure
+ *     (CHOL_ERR_*).  The reference treats any value != 0 as failure
+ *     (W2:243, 327, 420).
+ *   - There is NO CPU backend.  chol_init(ncpu, 0) fails with CHOL_ERR_NO_GPU:
+ *     the product path never falls back to host arithmetic.
+ *   - Storage: a descriptor's `mat` may be NULL (the library allocates HBM in
+ *     Chameleon tile layout, V6:44), a device pointer (wrapped in place, tiles
+ *     stay resident) or a host pointer (W2:78: staged H2D/D2H around every
+ *     call, which is what the reference's worker does with its blobs).
+ *   - Tile layout (Chameleon descriptor): tile (I,J) of an lmt x lnt tile grid
+ *     is `bsiz` contiguous elements at offset (I + J*lmt)*bsiz, column-major
+ *     inside with leading dimension mb.  With p*q > 1 each process holds the
+ *     tiles with (I mod p, J mod q) == its grid coordinates, packed the same
+ *     way over local tile indices (I/p, J/q).
+ */
+#ifndef CHOLMI_H
+#define CHOLMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Chameleon / PLASMA enum values (ChamRealDouble etc. are referenced at W2:78,
+ * 238, 323, 416, 511; chameleon.h itself is not in the reference tree). */
+enum {
+  CHOL_REAL_FLOAT = 2,  /* ChamRealFloat  */
+  CHOL_REAL_DOUBLE = 3, /* ChamRealDouble */
+  CHOL_NOTRANS = 111,   /* ChamNoTrans */
+  CHOL_TRANS = 112,     /* ChamTrans   */
+  CHOL_UPPER = 121,     /* ChamUpper   */
+  CHOL_LOWER = 122,     /* ChamLower   */
+  CHOL_NONUNIT = 131,   /* ChamNonUnit */
+  CHOL_UNIT = 132,      /* ChamUnit    */
+  CHOL_LEFT = 141,      /* ChamLeft    */
+  CHOL_RIGHT = 142      /* ChamRight   */
+};
+
+enum {
+  CHOL_SUCCESS = 0,
+  CHOL_ERR_NOT_INITIALIZED = -101,
+  CHOL_ERR_NO_GPU = -102,        /* no HIP device / ngpu == 0 requested */
+  CHOL_ERR_HIP = -103,           /* a HIP runtime call failed (see chol_last_error) */
+  CHOL_ERR_NOT_SUPPORTED = -104, /* valid Chameleon usage this build does not cover */
+  CHOL_ERR_OUT_OF_MEMORY = -105
+};
+
+typedef struct chol_desc chol_desc_t;
+
+/* CHAMELEON_Init(ncpu, ngpu) W2:589, V6:41 / CHAMELEON_Finalize() V6:93.
+ * Process-global and idempotent.  `ncpu` is accepted for signature parity and
+ * ignored (host threads do no arithmetic); `ngpu` must be >= 1: this process
+ * drives HIP device `chol_set_device`'s value (default: $LOCAL_RANK or 0). */
+int chol_init(int ncpu, int ngpu);
+int chol_finalize(void);
+int chol_set_device(int device); /* call before chol_init */
+const char *chol_last_error(void);
+const char *chol_version(void);
+
+/* One process per GPU: position of this process in the p x q grid that
+ * descriptors with p*q > 1 refer to (Chameleon takes it from MPI).  rank =
+ * prow*q + pcol, i.e. tile (I,J) belongs to rank (I mod p)*q + (J mod q). */
+int chol_set_rank(int rank, int nranks);
+
+/* CHAMELEON_Desc_Create(&d, mat, dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q)
+ * W2:78 (1-tile wrap of a user buffer), V6:44 (mat = NULL: library-owned tile
+ * storage) / CHAMELEON_Desc_Destroy W2:256, V6:90-91. */
+int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm,
+                     int ln, int i, int j, int m, int n, int p, int q);
+int chol_desc_destroy(chol_desc_t **desc);
+
+/* CHAMELEON_dpotrf_Tile(uplo, A) W2:238, V6:56 (spotrf by descriptor dtype).
+ * Lower only.  Works on a 1-tile descriptor (worker path) and on a whole tiled
+ * matrix (driver path: the full wave DAG of C2:506-565 runs on the device). */
+int chol_potrf_tile(int uplo, chol_desc_t *A);
+
+/* CHAMELEON_dtrsm_Tile(side, uplo, trans, diag, alpha, A, B) W2:323.
+ * Supported: (Right, Lower, Trans, NonUnit), any alpha; 1-tile descriptors. */
+int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_desc_t *A,
+                   chol_desc_t *B);
+
+/* CHAMELEON_dsyrk_Tile(uplo, trans, alpha, A, beta, C) W2:416.
+ * Supported: (Lower, NoTrans), any alpha/beta; the strict upper triangle of C
+ * is never read or written. 1-tile descriptors. */
+int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *C);
+
+/* CHAMELEON_dgemm_Tile(transA, transB, alpha, A, B, beta, C) W2:511.
+ * Supported: (NoTrans, Trans), any alpha/beta. 1-tile descriptors. */
+int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
+                   double beta, chol_desc_t *C);
+
+/* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: fill a symmetric matrix with
+ * pseudo-random off-diagonal entries in [-0.5, 0.5) and `bump` added to the
+ * diagonal, directly in tile layout on the device.  Values depend only on
+ * (global row, global col, seed): independent of tile size and process grid. */
+int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed);
+
+/* CHAMELEON_Lapack_to_Tile / Tile_to_Lapack equivalents (host LAPACK layout
+ * <-> descriptor storage); single-process descriptors only. */
+int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *desc);
+int chol_tile_to_lapack(chol_desc_t *desc, void *A, int lda);
+
+/* Single-tile transfer for any descriptor this process owns tile (I,J) of. */
+int chol_tile_upload(chol_desc_t *desc, int I, int J, const void *host_tile);
+int chol_tile_download(chol_desc_t *desc, int I, int J, void *host_tile);
+
+/* ||tril(L) tril(L)^T - A||_F / ||A||_F with A regenerated by the plgsy rule
+ * (the check V6:72-87 intended).  L = factored descriptor. */
+int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel);
+
+/* ---- client-side host helpers (pure host code, usable without a GPU) ------ */
+/* make_spd_like_chameleon C2:224-252 + enforce_strict_diag_dominance C2:255-264 */
+void chol_make_spd_like_chameleon(double *A, int N, int LDA, double bump, char uplo,
+                                  unsigned long long seed);
+void chol_enforce_strict_diag_dominance(double *A, int N, int LDA, double eps);
+/* extract_block_from_spd_matrix_colmajor C2:280-309 */
+void chol_extract_block(const double *A, int N, int LDA, int B, int bi, int bj, double *block);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Device time (HIP events on the library's own streams) of the last whole-matrix
+ * chol_potrf_tile: total ms and the trailing-update kernel's launch count / ms. */
+int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launches,
+                          double *update_flops);
+/* 1 = record per-launch HIP events around the trailing-update kernel (serialises
+ * the streams; for bench.py's roofline leg only), 0 = off (default). */
+int chol_set_profiling(int on);
+
+/* ---- distributed (one process per GPU) building blocks -------------------- */
+/* Used by the Python driver that moves panel tiles with torch.distributed
+ * (RCCL).  All are asynchronous on the stream passed as `stream` (a hipStream_t
+ * cast to void*; NULL = the library's main stream).  `k` is the wave index. */
+void *chol_desc_local_ptr(chol_desc_t *desc, size_t *bytes);
+int chol_desc_local_tiles(chol_desc_t *desc, int *lmt, int *lnt);
+/* POTRF of tile (k,k) in place (owner only) and its 128-block inverses into the
+ * context workspace; `lkk` = device pointer to the tile. */
+int chol_wave_potrf(chol_desc_t *desc, int k, void *lkk, void *stream);
+/* After the diagonal tile arrived by broadcast on a non-owner: rebuild the
+ * 128-block inverses from the received L(k,k). */
+int chol_wave_invert_diag(chol_desc_t *desc, void *lkk, void *stream);
+/* TRSM of this process's tiles (i,k), i > k, against `lkk`. */
+int chol_wave_trsm(chol_desc_t *desc, int k, const void *lkk, void *stream);
+/* Trailing update of this process's tiles (i,j), j in [jlo, jhi), i >= j, i > k,
+ * with panel tile i read from panel_base[i % p] + (i/p - panel_first[i % p])*bsiz. */
+int chol_wave_update(chol_desc_t *desc, int k, int jlo, int jhi, const void *const *panel_base,
+                     const int *panel_first, void *stream);
+int chol_get_info(int *info); /* device-side POTRF status word of the current factorisation */
+int chol_reset_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHOLMI_H */

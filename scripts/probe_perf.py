@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Quick single-GPU timing probe of the resident whole-matrix POTRF (not the bench)."""
+import sys
+import time
+
+import os
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
+from dense_linear_app_amd import chameleon as ch
+
+
+def run(N, B, reps=3, dtype=None, check=True):
+    dtype = dtype or ch.ChamRealDouble
+    d = ch.CHAMELEON_Desc_Create(None, dtype, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+    best = 1e9
+    for r in range(reps + 1):
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+        t0 = time.perf_counter()
+        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+        dt = time.perf_counter() - t0
+        st = ch.last_potrf_stats()
+        if r > 0:
+            best = min(best, dt)
+        print(f"N={N} B={B} rep={r} info={info} wall={dt*1e3:.2f} ms dev={st['total_ms']:.2f} ms "
+              f"{N**3/3/dt/1e12:.2f} TF/s  upd_ms={st['update_ms']:.2f} upd_tf={st['update_flops']/max(st['update_ms'],1e-9)/1e9:.2f}", flush=True)
+    if check:
+        print("  residual", ch.residual_plgsy(d, float(N), 42), flush=True)
+    ch.CHAMELEON_Desc_Destroy(d)
+    return best
+
+
+if __name__ == "__main__":
+    ch.CHAMELEON_Init(1, 1)
+    cfgs = [(4096, 512), (16384, 512), (16384, 1024), (32768, 1024)]
+    if len(sys.argv) > 1:
+        cfgs = [tuple(map(int, a.split("x"))) for a in sys.argv[1:]]
+    for N, B in cfgs:
+        ch.set_profiling(False)
+        run(N, B, reps=2, check=(N <= 16384))
+        ch.set_profiling(True)
+        run(N, B, reps=1, check=False)

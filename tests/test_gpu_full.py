@@ -1,0 +1,132 @@
+"""GPU parity of the whole-matrix tiled POTRF (driver path, v6_test.c:44-56) against the
+CPU oracle's wave DAG on the same input, plus size-independent properties at scale.
+
+Stated tolerances: fp64 ||tril(L)tril(L)^T - A||_F/||A||_F <= 1e-13 and
+GPU-vs-oracle max|dL|/max|L| <= 1e-12; fp32 residual <= 5e-5, max|dL|/max|L| <= 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def full_desc(ch, N, B, dtype=None):
+    dtype = dtype or ch.ChamRealDouble
+    return ch.CHAMELEON_Desc_Create(None, dtype, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+
+
+@pytest.mark.parametrize("N,B", [(1024, 256), (1024, 128), (2048, 512), (3072, 1024)])
+def test_full_potrf_reference_input(cham, orc, N, B):
+    ch = cham
+    A = orc.reference_input(N)
+    d = full_desc(ch, N, B)
+    d.from_lapack(A)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(d.to_lapack())
+    Lref, info = orc.cholesky_lower(A, B)
+    assert info == 0
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-12
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-13
+    # strict upper tiles and the strict upper triangle of diagonal tiles are untouched
+    assert np.array_equal(np.triu(d.to_lapack(), 1), np.triu(A, 1))
+
+
+def test_full_potrf_golden_config1(cham):
+    """BASELINE config 1 (N=1024, B=256) against the committed scipy-replay fixture."""
+    from oracle import oracle as orc
+
+    ch = cham
+    g = np.load(os.path.join(GOLD, "dag_N1024_B256.npz"))
+    A = orc.reference_input(1024)
+    d = full_desc(ch, 1024, 256)
+    d.from_lapack(A)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(d.to_lapack())
+    scale = np.abs(g["diag"]).max()
+    assert np.abs(np.diag(L) - g["diag"]).max() / scale <= 1e-12
+    assert np.abs(L[g["probe_i"], g["probe_j"]] - g["probe_v"]).max() / scale <= 1e-12
+    fro = np.array([[np.linalg.norm(L[i * 256:(i + 1) * 256, j * 256:(j + 1) * 256]) for j in range(4)] for i in range(4)])
+    assert np.abs(fro - g["tile_fro"]).max() <= 1e-10
+
+
+def test_plgsy_matches_oracle_bits(cham, orc):
+    ch = cham
+    N, B = 1024, 256
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    T = orc.plgsy_tiles(N // B, B, float(N), 42)
+    A = orc.tile_to_lapack(T, N, B)
+    assert np.array_equal(d.to_lapack().view(np.uint64), A.view(np.uint64))
+    assert np.array_equal(A, A.T)
+
+
+@pytest.mark.parametrize("N,B", [(4096, 512), (8192, 1024)])
+def test_full_potrf_plgsy_vs_oracle(cham, orc, N, B):
+    ch = cham
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    res = ch.residual_plgsy(d, float(N), 42)
+    assert res <= 1e-13
+    T = orc.plgsy_tiles(N // B, B, float(N), 42)
+    assert orc.tiled_potrf(T, N // B, B) == 0
+    Lref = np.tril(orc.tile_to_lapack(T, N, B))
+    L = np.tril(d.to_lapack())
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-12
+
+
+def test_residual_kernel_detects_errors(cham):
+    """The on-device residual is a real check: a corrupted factor must fail it."""
+    ch = cham
+    N, B = 2048, 512
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 7)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    assert ch.residual_plgsy(d, float(N), 7) <= 1e-13
+    t = d.download_tile(2, 1)
+    t[5, 7] += 1e-3
+    d.upload_tile(2, 1, t)
+    assert ch.residual_plgsy(d, float(N), 7) > 1e-9
+
+
+def test_full_potrf_info(cham, orc):
+    """Non-SPD input: info = 1-based GLOBAL index of the failing pivot (LAPACK / W2:243)."""
+    ch = cham
+    N, B = 1024, 256
+    A = orc.reference_input(N)
+    A[700, 700] = -5.0
+    d = full_desc(ch, N, B)
+    d.from_lapack(A)
+    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+    _, iref = orc.cholesky_lower(A, B)
+    assert info == iref == 701
+
+
+def test_full_potrf_fp32(cham, orc):
+    ch = cham
+    N, B = 2048, 512
+    d = full_desc(ch, N, B, ch.ChamRealFloat)
+    ch.CHAMELEON_splgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_spotrf_Tile(ch.ChamLower, d) == 0
+    assert ch.residual_plgsy(d, float(N), 42) <= 5e-5
+    T = orc.plgsy_tiles(N // B, B, float(N), 42).astype(np.float32)
+    assert orc.tiled_potrf(T, N // B, B) == 0
+    Lref = np.tril(orc.tile_to_lapack(T.astype(np.float64), N, B))
+    L = np.tril(d.to_lapack().astype(np.float64))
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-4
+
+
+@pytest.mark.parametrize("N,B", [(16384, 512), (32768, 1024)])
+def test_full_potrf_large_properties(cham, N, B):
+    """BASELINE sizes: residual of the regenerated matrix, idempotent regeneration, positivity."""
+    ch = cham
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    assert ch.residual_plgsy(d, float(N), 42) <= 1e-13
+    for k in (0, N // B - 1):
+        t = d.download_tile(k, k)
+        assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
