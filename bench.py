@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp64 TFLOP/s of the N x N SPD tiled Cholesky (N^3/3 flops, the
+reference's metric, v6_test.c:60) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W            (default: N=65536, tile=1024, fp64)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 ...
+
+A step is one factorisation of a freshly generated matrix that is already resident in HBM
+in tile layout (generation is outside the timed region whenever K copies fit in HBM).
+The matrix is the same for every GPU count (counter-based generator), so the N-GPU runs
+factor the SAME problem: strong scaling.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK = 78.6   # TFLOP/s, MI355X dense fp64 matrix (datasheet)
+FP32_PEAK = 157.3  # TFLOP/s, MI355X dense fp32 matrix (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--N", type=int, default=65536)
+    ap.add_argument("--tile", type=int, default=1024)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-N", type=int, default=16384)
+    ap.add_argument("--cpu-tile", type=int, default=512)
+    ap.add_argument("--check", action="store_true", help="verify the residual of the last step (untimed)")
+    return ap.parse_args()
+
+
+def cpu_baseline(N: int, B: int, seed: int) -> dict:
+    """The CPU restatement of the reference path (oracle/, OpenMP over the tiles of a wave)
+    timed on this box's host cores on a bounded sample: one factorisation at (N, B)."""
+    from oracle import oracle as orc
+
+    nthreads = orc.num_threads()
+    T = orc.plgsy_tiles(N // B, B, float(N), seed)
+    t0 = time.perf_counter()
+    info = orc.tiled_potrf(T, N // B, B, nthreads)
+    dt = time.perf_counter() - t0
+    return {"value": round(N ** 3 / 3.0 / dt / 1e12, 5), "unit": "TFLOP/s", "cores": nthreads, "kind": "port",
+            "sample": f"one full factorisation N={N} tile={B} fp64 plgsy(seed={seed}), {dt:.2f} s, info={info}"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def run_single(a) -> dict:
+    import torch
+
+    from dense_linear_app_amd import chameleon as ch
+
+    ch.CHAMELEON_Init(1, 1)
+    N, B = a.N, a.tile
+    dt = ch.ChamRealDouble if a.dtype == "f64" else ch.ChamRealFloat
+    esz = 8 if a.dtype == "f64" else 4
+    free, _total = torch.cuda.mem_get_info()
+    mat_bytes = N * N * esz
+    copies = max(1, min(a.steps, int(0.85 * free // mat_bytes)))
+    descs = [ch.CHAMELEON_Desc_Create(None, dt, B, B, B * B, N, N, 0, 0, N, N, 1, 1) for _ in range(copies)]
+    regen_inside = copies < a.steps
+    ch.set_profiling(False)
+    for w in range(a.warmup):
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, descs[0], a.seed)
+        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, descs[0])
+        assert info == 0, info
+    for d in descs:
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
+    # timed region: exactly K steps; HIP events around every launch of the dominant kernel
+    ch.set_profiling(True)
+    upd_ms = upd_flops = 0.0
+    upd_launches = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        d = descs[s % copies]
+        if regen_inside and s >= copies:
+            ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
+        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+        st = ch.last_potrf_stats()
+        upd_ms += st["update_ms"]
+        upd_flops += st["update_flops"]
+        upd_launches += st["update_launches"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert info == 0, info
+    ch.set_profiling(False)
+    res = None
+    if a.check:
+        res = ch.residual_plgsy(descs[(a.steps - 1) % copies], float(N), a.seed)
+    for d in descs:
+        ch.CHAMELEON_Desc_Destroy(d)
+    return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
+            "regen_inside": regen_inside, "residual": res}
+
+
+def run_multi(a) -> dict:
+    import torch
+    import torch.distributed as dist
+
+    from dense_linear_app_amd import distributed as dd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    P, Q = dd.grid_for(world)
+    eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
+    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
+    for w in range(a.warmup):
+        eng.generate(float(a.N), a.seed)
+        info = chol.factorize()
+        assert info == 0, info
+    elapsed = 0.0
+    # the local part is small (N^2/world), but keep one buffer: regenerate between steps,
+    # bracket every step by barrier + synchronize and sum the K bracketed times
+    for s in range(a.steps):
+        eng.generate(float(a.N), a.seed)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        info = chol.factorize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed += time.perf_counter() - t0
+    assert info == 0, info
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = {"elapsed": float(t.item()), "rank": rank, "grid": f"{P}x{Q}"}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def main() -> int:
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 or world > 1:
+        r = run_multi(a)
+        if r["rank"] != 0:
+            return 0
+        grid = r["grid"]
+    else:
+        r = run_single(a)
+        grid = "1x1"
+    flops = a.N ** 3 / 3.0
+    ms_per_step = r["elapsed"] / a.steps * 1e3
+    tflops = flops * a.steps / r["elapsed"] / 1e12
+    peak = FP64_PEAK if a.dtype == "f64" else FP32_PEAK
+    line = {
+        "metric": "fp64 TFLOP/s for NxN SPD Cholesky (N^3/3 flops / factorisation time)" if a.dtype == "f64"
+        else "fp32 TFLOP/s for NxN SPD Cholesky (N^3/3 flops / factorisation time)",
+        "value": round(tflops, 3), "unit": "TFLOP/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"N={a.N} tile={a.tile} {a.dtype} SPD plgsy(bump=N, seed={a.seed}), lower, "
+                               f"resident in HBM in Chameleon tile layout", "N": a.N, "tile": a.tile,
+                   "grid": grid, "parallelism": f"2D block-cyclic {grid}"},
+        "pct_of_mfma_peak": round(100.0 * tflops / (peak * a.gpus), 2),
+    }
+    if a.gpus == 1:
+        if r.get("regen_inside"):
+            line["config"]["note"] = "matrix regenerated inside the timed region (copies did not fit)"
+        if r["upd_ms"] > 0:
+            ach = r["upd_flops"] / (r["upd_ms"] * 1e-3) / 1e12
+            traffic = load_pmc_traffic()
+            line["roofline"] = {
+                "bound": "mfma", "kernel": "k_trail_update", "achieved": round(ach, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": (traffic or {}).get("hbm_bytes_per_launch") if traffic and
+                traffic.get("N") == a.N and traffic.get("tile") == a.tile else None,
+                "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
+                "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
+            }
+        if r.get("residual") is not None:
+            line["residual"] = r["residual"]
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

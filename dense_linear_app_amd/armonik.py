@@ -1,0 +1,324 @@
+"""In-process stand-in for the ArmoniK client / worker SDK surface the reference uses.
+
+The SDK itself is not in the reference tree (it is cloned at image-build time,
+Dockerfile.worker.v4:92, Dockerfile.client.param.v1:28); this module restates only
+what the reference's call sites need, with the same names, argument meaning and
+error behaviour, so `client.py` and `worker.py` read like the reference files:
+
+  client side (client_distrib.cpp)          here
+  ----------------------------------------  -----------------------------------------
+  SessionsClient.create_session      :353   SessionsClient.create_session
+  ResultsClient.create_results_metadata:373 ResultsClient.create_results_metadata
+  ResultsClient.upload_result_data   :413   ResultsClient.upload_result_data
+  TasksClient.submit_tasks           :498   TasksClient.submit_tasks
+  EventsClient.wait_for_result_availability :499   EventsClient.wait_for_result_availability
+  TaskCreation{payload_id, expected_output_keys, data_dependencies} :489-492
+  TaskOptions (max_duration, max_retries, priority, partition, app) :331-339
+
+  worker side (worker_distrib.cpp)
+  ----------------------------------------
+  ArmoniKWorker::Execute(TaskHandler&) -> ProcessStatus   :95-99
+  TaskHandler.getPayload / getExpectedResults / getDataDependencies / send_result(...).get()
+                                                            :105, 180-186, 261
+  ProcessStatus::Ok / ProcessStatus(message)               :195, 267
+
+There is no gRPC, no object store and no network: the "control plane" is a Python
+object; results are write-once byte blobs held in host memory, tasks run as soon as
+their data dependencies are available, one at a time per worker (as an ArmoniK
+polling agent drives one Execute at a time, W2:593).
+"""
+from __future__ import annotations
+
+import uuid
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+
+# ------------------------------------------------------------------------------ value types
+@dataclass
+class TaskOptions:
+    """C2:331-339."""
+    max_duration_seconds: int = 3600
+    max_retries: int = 3
+    priority: int = 1
+    partition_id: str = ""
+    application_name: str = ""
+    application_version: str = ""
+    application_namespace: str = ""
+    options: Dict[str, str] = field(default_factory=dict)
+
+    def copy(self) -> "TaskOptions":
+        return TaskOptions(**{**self.__dict__, "options": dict(self.options)})
+
+
+@dataclass
+class TaskCreation:
+    """C2:489-492."""
+    payload_id: str = ""
+    expected_output_keys: List[str] = field(default_factory=list)
+    data_dependencies: List[str] = field(default_factory=list)
+
+
+class ProcessStatus:
+    """armonik::api::worker::ProcessStatus: Ok, or an error carrying a message."""
+    Ok: "ProcessStatus"
+
+    def __init__(self, details: str = "", _ok: bool = False):
+        self._ok = _ok
+        self._details = details
+
+    def ok(self) -> bool:
+        return self._ok
+
+    def details(self) -> str:
+        return self._details
+
+    def __repr__(self) -> str:
+        return "ProcessStatus::Ok" if self._ok else f"ProcessStatus({self._details!r})"
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, ProcessStatus) and (self._ok, self._details) == (other._ok, other._details)
+
+    def __hash__(self):
+        return hash((self._ok, self._details))
+
+
+ProcessStatus.Ok = ProcessStatus("", _ok=True)
+
+
+class ResultNotAvailable(RuntimeError):
+    """wait_for_result_availability on a result that was aborted or can never be produced."""
+
+
+class _Done:
+    """The future send_result returns (the reference awaits it with .get(), W2:261)."""
+
+    def __init__(self, exc: Optional[BaseException] = None):
+        self._exc = exc
+
+    def get(self):
+        if self._exc is not None:
+            raise self._exc
+
+
+# ------------------------------------------------------------------------------ worker side
+class TaskHandler:
+    def __init__(self, plane: "ControlPlane", session_id: str, task: "_Task"):
+        self._plane, self._session, self._task = plane, session_id, task
+        self._deps = {rid: plane._results[rid].data for rid in task.data_dependencies}
+
+    def getPayload(self) -> str:
+        data = self._plane._results[self._task.payload_id].data
+        return bytes(data).decode("utf-8")
+
+    def getExpectedResults(self) -> List[str]:
+        return list(self._task.expected_output_keys)
+
+    def getDataDependencies(self) -> Dict[str, bytes]:
+        return self._deps
+
+    def getSessionId(self) -> str:
+        return self._session
+
+    def getTaskId(self) -> str:
+        return self._task.task_id
+
+    def getTaskOptions(self) -> TaskOptions:
+        return self._task.options
+
+    def send_result(self, result_id: str, data) -> _Done:
+        try:
+            if result_id not in self._task.expected_output_keys:
+                raise RuntimeError(f"result {result_id} is not an expected output of task {self._task.task_id}")
+            self._plane._complete_result(result_id, data)
+            return _Done()
+        except Exception as e:  # surfaced by .get(), like a failed gRPC upload
+            return _Done(e)
+
+
+class ArmoniKWorker:
+    """Base class: subclasses implement Execute(TaskHandler) -> ProcessStatus (W2:95-99)."""
+
+    def Execute(self, taskHandler: TaskHandler) -> ProcessStatus:  # noqa: N802 (reference name)
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------ control plane
+@dataclass
+class _Result:
+    result_id: str
+    name: str
+    session_id: str
+    data: Optional[bytes] = None
+    status: str = "created"  # created | completed | aborted
+
+
+@dataclass
+class _Task:
+    task_id: str
+    session_id: str
+    payload_id: str
+    expected_output_keys: List[str]
+    data_dependencies: List[str]
+    options: TaskOptions
+    status: str = "pending"  # pending | completed | error
+    output: Optional[ProcessStatus] = None
+    attempts: int = 0
+
+
+class ControlPlane:
+    """What stands between the four clients and the worker(s)."""
+
+    def __init__(self):
+        self._sessions: Dict[str, TaskOptions] = {}
+        self._results: Dict[str, _Result] = {}
+        self._tasks: Dict[str, _Task] = {}
+        self._pending: List[str] = []
+        self._workers: Dict[str, ArmoniKWorker] = {}
+        self.executed: List[str] = []  # task ids in execution order
+        self.on_task_done: Optional[Callable[[_Task], None]] = None
+
+    # -- deployment
+    def register_worker(self, partition_id: str, worker: ArmoniKWorker) -> None:
+        self._workers[partition_id] = worker
+
+    # -- internals
+    def _complete_result(self, result_id: str, data) -> None:
+        r = self._results.get(result_id)
+        if r is None:
+            raise KeyError(f"unknown result id {result_id}")
+        if r.status == "completed":
+            raise RuntimeError(f"result {result_id} is write-once and already has data")
+        r.data = bytes(data)
+        r.status = "completed"
+
+    def _ready(self, t: _Task) -> bool:
+        need = [t.payload_id] + t.data_dependencies
+        return all(self._results[r].status == "completed" for r in need)
+
+    def _blocked_forever(self, t: _Task) -> bool:
+        need = [t.payload_id] + t.data_dependencies
+        return any(self._results[r].status == "aborted" for r in need)
+
+    def _run(self, t: _Task) -> None:
+        worker = self._workers.get(t.options.partition_id)
+        if worker is None:
+            raise RuntimeError(f"no worker registered for partition {t.options.partition_id!r}")
+        while True:
+            t.attempts += 1
+            try:
+                status = worker.Execute(TaskHandler(self, t.session_id, t))
+            except Exception as e:  # a crashing worker: ArmoniK retries (max_retries, C2:335)
+                if t.attempts <= t.options.max_retries:
+                    continue
+                status = ProcessStatus(f"worker crashed: {e}")
+            break
+        t.output = status
+        missing = [k for k in t.expected_output_keys if self._results[k].status != "completed"]
+        if status.ok() and not missing:
+            t.status = "completed"
+        else:
+            t.status = "error"
+            if status.ok():
+                t.output = ProcessStatus("task returned Ok without producing " + ",".join(missing))
+            for k in missing:
+                self._results[k].status = "aborted"
+        self.executed.append(t.task_id)
+        if self.on_task_done:
+            self.on_task_done(t)
+
+    def _pump(self) -> None:
+        progressed = True
+        while progressed:
+            progressed = False
+            for tid in list(self._pending):
+                t = self._tasks[tid]
+                if self._blocked_forever(t):
+                    t.status = "error"
+                    t.output = ProcessStatus("a data dependency was aborted")
+                    for k in t.expected_output_keys:
+                        self._results[k].status = "aborted"
+                    self._pending.remove(tid)
+                    progressed = True
+                elif self._ready(t):
+                    self._pending.remove(tid)
+                    self._run(t)
+                    progressed = True
+
+
+# ------------------------------------------------------------------------------ client side
+class SessionsClient:
+    def __init__(self, plane: ControlPlane):
+        self._plane = plane
+
+    def create_session(self, default_task_option: TaskOptions, partitions: Sequence[str] = ()) -> str:
+        sid = str(uuid.uuid4())
+        self._plane._sessions[sid] = default_task_option.copy()
+        return sid
+
+
+class ResultsClient:
+    def __init__(self, plane: ControlPlane):
+        self._plane = plane
+
+    def create_results_metadata(self, session_id: str, names: Iterable[str]) -> Dict[str, str]:
+        """name -> fresh result id (C2:373, 471).  Results are write-once."""
+        if session_id not in self._plane._sessions:
+            raise KeyError(f"unknown session {session_id}")
+        out = {}
+        for n in names:
+            rid = str(uuid.uuid4())
+            self._plane._results[rid] = _Result(rid, n, session_id)
+            out[n] = rid
+        return out
+
+    def upload_result_data(self, session_id: str, result_id: str, data) -> None:
+        if isinstance(data, str):
+            data = data.encode("utf-8")
+        self._plane._complete_result(result_id, data)
+        self._plane._pump()
+
+    def download_result_data(self, session_id: str, result_id: str) -> bytes:
+        r = self._plane._results[result_id]
+        if r.status != "completed":
+            raise ResultNotAvailable(f"result {result_id} is {r.status}")
+        return r.data
+
+
+class TasksClient:
+    def __init__(self, plane: ControlPlane):
+        self._plane = plane
+
+    def submit_tasks(self, session_id: str, task_creations: Sequence[TaskCreation],
+                     task_options: Optional[TaskOptions] = None) -> List[str]:
+        opts = task_options or self._plane._sessions[session_id]
+        ids = []
+        for tc in task_creations:
+            for rid in [tc.payload_id, *tc.expected_output_keys, *tc.data_dependencies]:
+                if rid not in self._plane._results:
+                    raise KeyError(f"submit_tasks: unknown result id {rid}")
+            tid = str(uuid.uuid4())
+            self._plane._tasks[tid] = _Task(tid, session_id, tc.payload_id, list(tc.expected_output_keys),
+                                            list(tc.data_dependencies), opts.copy())
+            self._plane._pending.append(tid)
+            ids.append(tid)
+        self._plane._pump()
+        return ids
+
+    def get_task_output(self, task_id: str) -> Optional[ProcessStatus]:
+        return self._plane._tasks[task_id].output
+
+
+class EventsClient:
+    def __init__(self, plane: ControlPlane):
+        self._plane = plane
+
+    def wait_for_result_availability(self, session_id: str, result_ids: Sequence[str]) -> None:
+        self._plane._pump()
+        for rid in result_ids:
+            r = self._plane._results[rid]
+            if r.status == "completed":
+                continue
+            producer = next((t for t in self._plane._tasks.values() if rid in t.expected_output_keys), None)
+            why = producer.output.details() if producer and producer.output else "no task produces it yet"
+            raise ResultNotAvailable(f"result {rid} is {r.status}: {why}")

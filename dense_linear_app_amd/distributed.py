@@ -1,0 +1,243 @@
+"""2D block-cyclic tiled Cholesky over several MI355X, one process per GPU.
+
+Partitioning is Chameleon's own descriptor rule (p x q process grid, always 1 x 1 in the
+reference: worker_distrib.cpp:77, v6_test.c:26-27): tile (I,J) lives on rank
+(I mod P)*Q + (J mod Q); each rank stores its tiles packed over (I/P, J/Q).  Owner
+computes.  The wave DAG is the reference client's (client_distrib.cpp:506-565); what
+moves between GPUs per wave k is
+
+  1. L(k,k): from its owner to the other ranks of process column k mod Q (they hold the
+     rest of panel k and need it for their TRSMs);
+  2. panel k, i.e. the tiles L(i,k), i > k: every one of the P ranks of that process column
+     broadcasts its part (contiguous in its local storage, so no packing) to all ranks;
+     each rank then runs its local SYRK/GEMM updates from the replicated panel.
+
+The collectives are torch.distributed broadcasts (backend "nccl" = RCCL over xGMI on the
+GPUs, "gloo" in the CPU tests).  There is no all-reduce anywhere.  Panel k+1 is factored
+and broadcast on a side stream while the bulk of update k runs (one wave of lookahead),
+and its receive buffers are double-buffered by wave parity.
+
+The wave logic is written against a small `engine` interface so that the CPU tests can
+drive it with world_size 2 on gloo; the product engine is `HipEngine` (libcholmi.so,
+no fallback).
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def grid_for(nranks: int) -> Tuple[int, int]:
+    """1x1, 1x2, 2x2, 2x4 for 1/2/4/8 GPUs; P <= Q in general."""
+    p = int(math.isqrt(nranks))
+    while nranks % p:
+        p -= 1
+    return p, nranks // p
+
+
+def owner_of(I: int, J: int, P: int, Q: int) -> int:
+    return (I % P) * Q + (J % Q)
+
+
+def first_local_row_above(k: int, prow: int, P: int) -> int:
+    """Local index of the first tile row i > k with i mod P == prow."""
+    return (k + P - prow) // P
+
+
+class HipEngine:
+    """This rank's tiles in HBM + the wave-level kernels of libcholmi.so."""
+
+    def __init__(self, N: int, B: int, P: int, Q: int, rank: int, dtype: str = "f64", device: Optional[int] = None):
+        import torch
+
+        from . import chameleon as ch
+        from ._lib import check, lib
+
+        self.torch, self.ch, self._lib, self._check = torch, ch, lib(), check
+        assert N % B == 0
+        self.N, self.B, self.P, self.Q, self.rank = N, B, P, Q, rank
+        self.nt = N // B
+        self.prow, self.pcol = rank // Q, rank % Q
+        self.tdtype = torch.float64 if dtype == "f64" else torch.float32
+        self.cdtype = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
+        if device is not None:
+            ch.set_device(device)
+        ch.set_rank(rank, P * Q)
+        ch.CHAMELEON_Init(1, 1)
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.lmt = max(0, (self.nt - self.prow + P - 1) // P)
+        self.lnt = max(0, (self.nt - self.pcol + Q - 1) // Q)
+        self.bsiz = B * B
+        self.store = torch.empty(max(1, self.lmt * self.lnt) * self.bsiz, dtype=self.tdtype, device=self.dev)
+        self.desc = ch.CHAMELEON_Desc_Create(self.store, self.cdtype, B, B, self.bsiz, N, N, 0, 0, N, N, P, Q)
+        assert self.desc.local_tiles() == (self.lmt, self.lnt)
+
+    # -- storage
+    def empty_tiles(self, n: int):
+        return self.torch.empty(max(1, n) * self.bsiz, dtype=self.tdtype, device=self.dev)
+
+    def tiles_view(self, il: int, jl: int, count: int = 1):
+        off = (il + jl * self.lmt) * self.bsiz
+        return self.store[off:off + count * self.bsiz]
+
+    def generate(self, bump: float, seed: int) -> None:
+        self.ch.CHAMELEON_dplgsy_Tile(bump, self.ch.ChamLower, self.desc, seed)
+
+    def upload_tile(self, I: int, J: int, tile: np.ndarray) -> None:
+        self.desc.upload_tile(I, J, tile)
+
+    def download_tile(self, I: int, J: int) -> np.ndarray:
+        return self.desc.download_tile(I, J)
+
+    # -- streams
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.dev, priority=-1)
+
+    def main_stream(self):
+        return self.torch.cuda.current_stream(self.dev)
+
+    def stream_ctx(self, s):
+        return self.torch.cuda.stream(s)
+
+    def wait(self, waiter, waited) -> None:
+        waiter.wait_stream(waited)
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.dev)
+
+    # -- wave kernels (asynchronous on stream s)
+    def _sp(self, s):
+        return C.c_void_p(s.cuda_stream)
+
+    def potrf(self, k: int, lkk, s) -> None:
+        self._check("chol_wave_potrf", self._lib.chol_wave_potrf(self.desc.handle, k, lkk.data_ptr(), self._sp(s)))
+
+    def invert_diag(self, lkk, s) -> None:
+        self._check("chol_wave_invert_diag",
+                    self._lib.chol_wave_invert_diag(self.desc.handle, lkk.data_ptr(), self._sp(s)))
+
+    def trsm(self, k: int, lkk, s) -> None:
+        self._check("chol_wave_trsm", self._lib.chol_wave_trsm(self.desc.handle, k, lkk.data_ptr(), self._sp(s)))
+
+    def update(self, k: int, jlo: int, jhi: int, bases: Sequence, firsts: Sequence[int], s) -> None:
+        pb = (C.c_void_p * self.P)(*[b.data_ptr() for b in bases])
+        pf = (C.c_int * self.P)(*firsts)
+        self._check("chol_wave_update",
+                    self._lib.chol_wave_update(self.desc.handle, k, jlo, jhi, pb, pf, self._sp(s)))
+
+    def reset_info(self) -> None:
+        self._check("chol_reset_info", self._lib.chol_reset_info())
+
+    def info(self) -> int:
+        v = C.c_int()
+        self._check("chol_get_info", self._lib.chol_get_info(C.byref(v)))
+        return v.value
+
+    def destroy(self) -> None:
+        self.ch.CHAMELEON_Desc_Destroy(self.desc)
+
+
+class BlockCyclicCholesky:
+    """The distributed wave loop.  `dist` is torch.distributed (already initialised)."""
+
+    def __init__(self, engine, dist, lookahead: bool = True):
+        self.e, self.dist, self.lookahead = engine, dist, lookahead
+        e = engine
+        self.world = dist.get_world_size()
+        assert self.world == e.P * e.Q and dist.get_rank() == e.rank
+        # one group per process column (for L(k,k)); every rank must create every group
+        self.col_groups = []
+        for qc in range(e.Q):
+            ranks = [pr * e.Q + qc for pr in range(e.P)]
+            self.col_groups.append(dist.new_group(ranks=ranks) if e.P > 1 else None)
+        maxpart = (e.nt + e.P - 1) // e.P
+        # receive buffers: [parity][process row]
+        self.pbuf = [[e.empty_tiles(maxpart) for _ in range(e.P)] for _ in range(2)]
+        self.lkk_buf = [e.empty_tiles(1) for _ in range(2)]
+
+    # -- one panel: POTRF(k,k), its broadcast down the process column, TRSMs, panel broadcast
+    def _panel(self, k: int, s):
+        e, dist = self.e, self.dist
+        P, Q = e.P, e.Q
+        pr, pc = k % P, k % Q
+        par = k & 1
+        in_col = (e.pcol == pc)
+        lkk = None
+        if in_col:
+            if e.prow == pr:
+                lkk = e.tiles_view(k // P, k // Q)
+                e.potrf(k, lkk, s)
+            else:
+                lkk = self.lkk_buf[par]
+            if P > 1 and k + 1 < e.nt:
+                dist.broadcast(lkk, src=pr * Q + pc, group=self.col_groups[pc])
+                if e.prow != pr:
+                    e.invert_diag(lkk, s)
+            if k + 1 < e.nt:
+                e.trsm(k, lkk, s)
+        bases, firsts = [], []
+        for p2 in range(P):
+            il0 = first_local_row_above(k, p2, P)
+            cnt = max(0, (e.nt - p2 + P - 1) // P - il0)
+            src = p2 * Q + pc
+            if e.rank == src:
+                buf = e.tiles_view(il0, k // Q, cnt) if cnt > 0 else self.pbuf[par][p2][:0]
+            else:
+                buf = self.pbuf[par][p2][:cnt * e.bsiz]
+            if cnt > 0 and self.world > 1:
+                dist.broadcast(buf, src=src)
+            bases.append(buf if cnt > 0 else self.pbuf[par][p2])
+            firsts.append(il0)
+        return bases, firsts
+
+    def factorize(self) -> int:
+        """In place on the engine's tiles.  Returns LAPACK info (max over ranks)."""
+        e = self.e
+        main = e.main_stream()
+        side = e.new_stream() if self.lookahead else main
+        e.reset_info()
+        e.wait(side, main)
+        with e.stream_ctx(side):
+            panel = self._panel(0, side)
+        for k in range(e.nt - 1):
+            e.wait(main, side)  # panel k complete (and received) before it is used
+            bases, firsts = panel
+            if self.lookahead:
+                # column k+1 first, so that panel k+1 can start under the rest of update k
+                e.update(k, k + 1, k + 2, bases, firsts, main)
+                e.wait(side, main)
+                with e.stream_ctx(side):
+                    panel = self._panel(k + 1, side)
+                e.update(k, k + 2, e.nt, bases, firsts, main)
+            else:
+                e.update(k, k + 1, e.nt, bases, firsts, main)
+                panel = self._panel(k + 1, main)
+        e.wait(main, side)
+        e.synchronize()
+        info = e.info()
+        if self.world > 1:
+            import torch
+
+            # the smallest positive info wins: MAX-reduce (2^40 - info), 0 = success
+            v = (1 << 40) - info if info > 0 else 0
+            t = torch.tensor([v], dtype=torch.int64, device=getattr(e, "dev", "cpu"))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            v = int(t.item())
+            info = 0 if v == 0 else (1 << 40) - v
+        return info
+
+
+def run(N: int, B: int, dist, dtype: str = "f64", seed: int = 42, bump: Optional[float] = None,
+        lookahead: bool = True, engine=None):
+    """Generate the plgsy matrix (v6_test.c:46: bump = N) over the grid and factor it."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    P, Q = grid_for(world)
+    if engine is None:
+        engine = HipEngine(N, B, P, Q, rank, dtype)
+    engine.generate(float(N) if bump is None else bump, seed)
+    chol = BlockCyclicCholesky(engine, dist, lookahead)
+    return chol, engine

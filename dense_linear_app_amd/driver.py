@@ -1,0 +1,136 @@
+"""Whole-matrix resident driver: the reference's single-node Chameleon driver and its
+benchmark protocol, on one MI355X.
+
+Mirrors Cholesky_chameleon_VM/cho/docker_installation_and_bench_files/v6_test.c ("V6")
+and benchmark.c ("BN"):
+
+  v6_test(argv)   V6:7-95   16 positional arguments, CHAMELEON_Init -> Desc_Create(NULL) ->
+                            dplgsy_Tile(bump=N, seed) -> timed dpotrf_Tile -> "Performance: %.2f
+                            Gflop/s" with N^3/3 flops (V6:60) -> validation -> cleanup; exit code
+                            = (info != 0) (V6:95)
+  bench(...)      BN:103, 201, 282-285   1 warm-up ("calibration") + 7 timed repeats per (N, NB),
+                            CSV columns timestamp,scheduler,mapping,ncpu,ngpu,N,NB,run_idx,ms,
+                            exit_code,gflops,rel_error (+ tflops,pct_peak,dtype)
+
+The validation line is the check V6:72-87 *meant* (||A - L L^T|| / ||A||, Frobenius, on the
+device, with A regenerated): the reference's version multiplies L^T L (dlauum) and
+compares a triangle with the full matrix, and fails on every published row.
+"""
+from __future__ import annotations
+
+import csv
+import os
+import sys
+import time
+from typing import Optional, Sequence
+
+from . import chameleon as ch
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet, dense fp64 matrix
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X datasheet, dense fp32 matrix
+
+USAGE = ("Usage: %s <num_cpu> <num_gpu> <matrix_size_N> <tile_size_NB> <mb> <nb> <bsiz> <lm> <ln> "
+         "<ioff> <joff> <m> <n> <p> <q> <seed>\n")
+
+
+def _atoi(s: str) -> int:
+    """C atoi: leading whitespace, optional sign, digits; anything else -> 0."""
+    s = s.strip()
+    n = 0
+    sign = 1
+    i = 0
+    if s[:1] in "+-":
+        sign = -1 if s[0] == "-" else 1
+        i = 1
+    while i < len(s) and s[i].isdigit():
+        n = n * 10 + int(s[i])
+        i += 1
+    return sign * n
+
+
+def potrf_timed(desc: ch.Desc) -> tuple[int, float]:
+    """V6:54-59: monotonic clock around the (synchronous) factorisation call."""
+    t0 = time.perf_counter()
+    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, desc)
+    return info, time.perf_counter() - t0
+
+
+def v6_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr, dtype: int = ch.ChamRealDouble) -> int:
+    """V6:7-95.  `argv` excludes the program name.  Returns the process exit code."""
+    if len(argv) < 16:
+        err.write(USAGE % "v6_test")
+        return 1
+    ncpu, ngpu, N, NB, mb, nb, bsiz, lm, ln, ioff, joff, m, n, p, q, seed = (_atoi(a) for a in argv[:16])
+    if bsiz != mb * nb:
+        err.write(f"Warning: bsiz ({bsiz}) != mb*nb ({mb * nb})\n")
+    print(f"[setup] ncpu={ncpu} ngpu={ngpu} N={N} NB={NB} scheduler=hip-streams", file=out)
+    ch.CHAMELEON_Init(ncpu, ngpu)
+    descA = ch.CHAMELEON_Desc_Create(None, dtype, mb, nb, bsiz, lm, ln, ioff, joff, m, n, p, q)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, descA, seed)
+    info, time_sec = potrf_timed(descA)
+    gflops = (1.0 / 3.0) * float(N) ** 3 / (time_sec * 1e9)
+    print(f"N = {N}, NB = {NB}", file=out)
+    print(f"Time: {time_sec:.3f} s", file=out)
+    print(f"Performance: {gflops:.2f} Gflop/s", file=out)
+    if info != 0:
+        err.write(f"Erreur dans CHAMELEON_dpotrf_Tile: {info}\n")
+        rel = float("nan")
+    else:
+        rel = ch.residual_plgsy(descA, float(N), seed)
+    print(f"||A - LL^T||_F / ||A||_F = {rel:.2e}", file=out)
+    print("Validation numérique : %s" % ("PASS" if rel < 1e-10 else "FAIL"), file=out)
+    ch.CHAMELEON_Desc_Destroy(descA)
+    return int(info != 0)
+
+
+CSV_HEADER = ["timestamp", "scheduler", "mapping", "ncpu", "ngpu", "N", "NB", "run_idx", "ms", "exit_code",
+              "gflops", "rel_error", "tflops", "pct_peak", "dtype"]
+
+
+def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None, repeats: int = 8,
+          dtype: int = ch.ChamRealDouble, seed: int = 42, out=sys.stdout) -> list[dict]:
+    """BN:76-285: for every (N, NB): run 0 is the warm-up (the reference's StarPU calibration
+    run, BN:201), runs 1..repeats-1 are measured; one CSV row per run."""
+    ch.CHAMELEON_Init(os.cpu_count() or 1, 1)
+    peak = FP64_MFMA_PEAK_TFLOPS if dtype == ch.ChamRealDouble else FP32_MFMA_PEAK_TFLOPS
+    rows = []
+    f = w = None
+    if csv_path:
+        os.makedirs(os.path.dirname(os.path.abspath(csv_path)) or ".", exist_ok=True)
+        new = not os.path.exists(csv_path) or os.path.getsize(csv_path) == 0
+        f = open(csv_path, "a", newline="")
+        w = csv.writer(f)
+        if new:
+            w.writerow(CSV_HEADER)
+    for N in Ns:
+        for NB in NBs:
+            if N % NB:
+                continue
+            d = ch.CHAMELEON_Desc_Create(None, dtype, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1)
+            for r in range(repeats):
+                ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, seed)
+                info, secs = potrf_timed(d)
+                rel = ch.residual_plgsy(d, float(N), seed) if (info == 0 and r == repeats - 1) else -1.0
+                gf = N ** 3 / 3.0 / secs / 1e9
+                row = dict(timestamp=time.strftime("%Y-%m-%d %H:%M:%S"), scheduler="hip-streams", mapping="1gpu",
+                           ncpu=0, ngpu=1, N=N, NB=NB, run_idx=r, ms=int(round(secs * 1e3)), exit_code=int(info != 0),
+                           gflops=f"{gf:.6f}", rel_error=f"{rel:.6e}", tflops=f"{gf / 1e3:.4f}",
+                           pct_peak=f"{100 * gf / 1e3 / peak:.2f}", dtype="f64" if dtype == ch.ChamRealDouble else "f32")
+                rows.append(row)
+                if w:
+                    w.writerow([row[k] for k in CSV_HEADER])
+                    f.flush()
+                print(f"   -> N={N} NB={NB} run={r} ms={secs * 1e3:.2f}  GF={gf:.2f}  err={rel:.2e}  exit={int(info != 0)}",
+                      file=out)
+            ch.CHAMELEON_Desc_Destroy(d)
+    if f:
+        f.close()
+    return rows
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    return v6_test(sys.argv[1:] if argv is None else argv)
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,202 @@
+"""CPU-side tests of the product's host layer: the C-ABI library loads and exports what
+include/cholmi.h declares, the client's input construction / parameter parsing / payload
+schema match the reference's golden vectors, and the worker + in-process task API follow
+worker_distrib.cpp's contract (error strings, ordering, write-once results).  The tile
+arithmetic is injected from the oracle here (tests only): no GPU compute is attempted."""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from dense_linear_app_amd import _lib, armonik as ak, client
+from dense_linear_app_amd.worker import DagCholeskyWorker, handle_json
+
+from oracle_engine import OracleTileBackend
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G = json.load(open(os.path.join(GOLD, "golden_inputs.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.asfortranarray(a).tobytes(order="F")).hexdigest()
+
+
+# ------------------------------------------------------------------ the boundary
+def test_library_loads_and_exports_header_symbols():
+    L = _lib.lib()
+    syms = _lib.abi_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/cholmi.h but not exported"
+    assert b"gfx950" in L.chol_version()
+
+
+def test_no_cpu_backend():
+    """chol_init(ncpu, 0) must refuse: the product never computes on the host."""
+    L = _lib.lib()
+    assert L.chol_init(4, 0) == -102
+    assert b"no CPU backend" in L.chol_last_error()
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.join(os.path.dirname(__file__), "..", "dense_linear_app_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "libchol_oracle" not in text, f
+
+
+# ------------------------------------------------------------------ client: inputs
+@pytest.mark.parametrize("case", sorted(G["cases"]))
+def test_client_input_construction_matches_reference(case):
+    c = G["cases"][case]
+    N, B = c["N"], c["B"]
+    A = client.make_spd_like_chameleon(N, 100.0, "L", 12345)
+    assert sha(A) == c["sha_A_before_dominance"]
+    client.enforce_strict_diag_dominance(A)
+    assert sha(A) == c["sha_A"]
+    for name, h in c["tiles_sha"].items():
+        _, i, j = name.split("/")
+        assert name == client.block_id_from_ij(int(i), int(j))
+        assert sha(client.extract_block_from_spd_matrix_colmajor(A, N, B, int(i), int(j))) == h
+
+
+def test_client_upper_variant_and_ids():
+    assert sha(client.make_spd_like_chameleon(12, 100.0, "U", 12345)) == G["upper_N12_sha"]
+    for k, v in G["block_ids"].items():
+        i, j = map(int, k.split(","))
+        assert client.block_id_from_ij(i, j) == v
+
+
+def test_load_params_matches_reference():
+    err = io.StringIO()
+    for c in G["load_params"]:
+        p = client.load_params(c["argv"], env={}, err=err)
+        assert [p.N, p.B] == c["NB"], c
+    env = G["load_params_env"]["env"]
+    for c in G["load_params_env"]["cases"]:
+        p = client.load_params(c["argv"], env=env, err=err)
+        assert [p.N, p.B] == c["NB"], c
+    for c in G["parse_int_str"]:
+        assert client.parse_int_str(c["s"], c["fallback"], "t", err) == c["value"], c
+    assert "[CONFIG] Ignoring invalid value for --N='abc', using 12" in err.getvalue()
+
+
+def test_payload_schema():
+    """C1:44-97 field names/order; example of C2:100-103."""
+    assert client.make_payload_potrf("id0", 4) == '{"op":"POTRF","B":4,"in":"id0"}'
+    assert client.make_payload_trsm("L", "A", 4) == '{"op":"TRSM","B":4,"inL":"L","inA":"A"}'
+    assert client.make_payload_syrk("C", "A", 4) == '{"op":"SYRK","B":4,"inC":"C","inA":"A"}'
+    assert (client.make_payload_gemm("5c60", "7f3a", "9a7c", 448)
+            == '{"op":"GEMM","B":448,"inC":"5c60","inAi":"7f3a","inAj":"9a7c"}')
+    p = handle_json(client.make_payload("GEMM", ["c", "ai", "aj"], 8))
+    assert (p.op, p.B, p.inC, p.inAi, p.inAj) == ("GEMM", 8, "c", "ai", "aj")
+    # explicit routing: a TRSM stays a TRSM whatever the ids look like (C2:175 defect)
+    assert handle_json(client.make_payload("TRSM", ["5d99-uuid", "ef13-uuid"], 4)).op == "TRSM"
+    with pytest.raises(RuntimeError):
+        client.make_payload("TRSM", ["only-one"], 4)
+
+
+# ------------------------------------------------------------------ worker contract
+def _plane_with(worker):
+    plane = ak.ControlPlane()
+    plane.register_worker(client.PARTITION, worker)
+    sid = ak.SessionsClient(plane).create_session(client.default_task_options(), [client.PARTITION])
+    return plane, sid
+
+
+def _submit(plane, sid, payload, deps, blobs):
+    rc, tc = ak.ResultsClient(plane), ak.TasksClient(plane)
+    ids = rc.create_results_metadata(sid, ["output", "payload"] + list(blobs))
+    for name, data in blobs.items():
+        rc.upload_result_data(sid, ids[name], data)
+    payload = payload.format(**ids)
+    rc.upload_result_data(sid, ids["payload"], payload)
+    tid = tc.submit_tasks(sid, [ak.TaskCreation(ids["payload"], [ids["output"]], [ids[d] for d in deps])],
+                          client.default_task_options())[0]
+    return ids, tc.get_task_output(tid)
+
+
+def test_worker_error_strings():
+    w = DagCholeskyWorker(backend=OracleTileBackend())
+    plane, sid = _plane_with(w)
+    tile = np.eye(4).tobytes()
+    # missing dependency: payload names an id that is not among the task's data dependencies
+    ids, st = _submit(plane, sid, '{{"op":"POTRF","B":4,"in":"nope"}}', [], {})
+    assert not st.ok() and st.details() == "[Worker][POTF] Missing dependency: nope"
+    ids, st = _submit(plane, sid, '{{"op":"TRSM","B":4,"inL":"{a}","inA":"zz"}}', ["a"], {"a": tile})
+    assert st.details() == "[Worker][TRSM] Missing dependency: zz"
+    ids, st = _submit(plane, sid, '{{"op":"SYRK","B":4,"inC":"cc","inA":"{a}"}}', ["a"], {"a": tile})
+    assert st.details() == " [Worker][SYRK]Missing dependency: cc"  # sic (W2:370)
+    ids, st = _submit(plane, sid, '{{"op":"GEMM","B":4,"inC":"{a}","inAi":"{a}","inAj":"q"}}', ["a"], {"a": tile})
+    assert st.details() == "[Worker][GEMM] Missing dependency: q"
+    # bad block size (W2:218-220)
+    ids, st = _submit(plane, sid, '{{"op":"POTRF","B":4,"in":"{a}"}}', ["a"], {"a": np.ones(15).tobytes()})
+    assert st.details() == "[Worker][POTF] Bad block size: expected 16 doubles, got 15"
+    # info != 0 -> exception text (W2:243-244, 558-560)
+    bad = np.eye(4)
+    bad[2, 2] = -1
+    ids, st = _submit(plane, sid, '{{"op":"POTRF","B":4,"in":"{a}"}}', ["a"], {"a": bad.tobytes()})
+    assert st.details() == "Exception: [Worker][POTF] dpotrf info=3"
+    ids, st = _submit(plane, sid, '{{"op":"LU","B":4}}', [], {})
+    assert st.details() == "Unknown op=LU"
+    ids, st = _submit(plane, sid, "not json", [], {})
+    assert st.details().startswith("Exception: ")
+    # a failed task aborts its output: waiting on it raises
+    with pytest.raises(ak.ResultNotAvailable):
+        ak.EventsClient(plane).wait_for_result_availability(sid, [ids["output"]])
+    # success path: output blob = raw column-major doubles (W2:251-261)
+    ids, st = _submit(plane, sid, '{{"op":"POTRF","B":4,"in":"{a}"}}', ["a"], {"a": (4 * np.eye(4)).tobytes()})
+    assert st == ak.ProcessStatus.Ok
+    out = np.frombuffer(ak.ResultsClient(plane).download_result_data(sid, ids["output"]))
+    assert np.array_equal(out.reshape(4, 4), 2 * np.eye(4))
+
+
+def test_results_are_write_once():
+    plane, sid = _plane_with(DagCholeskyWorker(backend=OracleTileBackend()))
+    rc = ak.ResultsClient(plane)
+    rid = rc.create_results_metadata(sid, ["x"])["x"]
+    rc.upload_result_data(sid, rid, b"abc")
+    with pytest.raises(RuntimeError):
+        rc.upload_result_data(sid, rid, b"def")
+
+
+def test_client_dag_default_case_matches_golden():
+    """C1/C2 default N=12, B=4: 3 waves, 3/3/3/1 tasks; factor equals the committed fixture."""
+    res = client.run_cholesky_dag(12, 4, worker=DagCholeskyWorker(backend=OracleTileBackend()))
+    assert res.task_counts == {"POTRF": 3, "TRSM": 3, "SYRK": 3, "GEMM": 1}
+    g = np.load(os.path.join(GOLD, "dag_N12_B4.npz"))
+    assert np.abs(res.lower_factor() - g["L"]).max() <= 1e-13
+
+
+def test_client_dag_config1_plumbing():
+    """BASELINE config 1 (4x4 tiles of 256): 20 tasks 4/6/6/4 in the reference's order."""
+    order = []
+    w = DagCholeskyWorker(backend=OracleTileBackend())
+    plane = ak.ControlPlane()
+    orig = w.Execute
+
+    def spy(th):
+        order.append(handle_json(th.getPayload()).op)
+        return orig(th)
+
+    w.Execute = spy
+    res = client.run_cholesky_dag(1024, 256, plane=plane, worker=w)
+    assert res.task_counts == {"POTRF": 4, "TRSM": 6, "SYRK": 6, "GEMM": 4}
+    assert order[:10] == ["POTRF", "TRSM", "TRSM", "TRSM", "SYRK", "GEMM", "SYRK", "GEMM", "GEMM", "SYRK"]
+    g = np.load(os.path.join(GOLD, "dag_N1024_B256.npz"))
+    L = res.lower_factor()
+    assert np.abs(np.diag(L) - g["diag"]).max() <= 1e-12
+    assert np.abs(L[g["probe_i"], g["probe_j"]] - g["probe_v"]).max() <= 1e-12
+
+
+def test_ragged_matrix_fails_like_the_reference():
+    """N not a multiple of B: the zero-padded last diagonal tile is singular (C2:285,299-303):
+    POTRF reports info > 0 and the client's wait fails."""
+    with pytest.raises(ak.ResultNotAvailable, match="dpotrf info=3"):
+        client.run_cholesky_dag(10, 4, worker=DagCholeskyWorker(backend=OracleTileBackend()))

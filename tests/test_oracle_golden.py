@@ -1,0 +1,138 @@
+"""The CPU oracle against the committed golden vectors (and, where /root/reference is
+mounted, against the reference's own functions compiled by oracle/build_ref.sh)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G = json.load(open(os.path.join(GOLD, "golden_inputs.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.asfortranarray(a).tobytes(order="F")).hexdigest()
+
+
+@pytest.mark.parametrize("case", sorted(G["cases"]))
+def test_input_generator_bit_exact(case):
+    c = G["cases"][case]
+    N, B = c["N"], c["B"]
+    raw = orc.make_spd_like_chameleon(N)
+    assert sha(raw) == c["sha_A_before_dominance"]
+    A = orc.enforce_strict_diag_dominance(raw)
+    assert sha(A) == c["sha_A"]
+    assert A[0, 0] == c["A00"] and A[1, 0] == c["A10"] and A[N - 1, N - 1] == c["Alast"]
+    assert float(A.sum()) == c["sum"]
+    assert [float(x) for x in orc.extract_block(A, B, 1, 0).ravel(order="F")[:4]] == c["blk_1_0_first4"]
+    for name, h in c["tiles_sha"].items():
+        _, i, j = name.split("/")
+        assert sha(orc.extract_block(A, B, int(i), int(j))) == h, name
+
+
+def test_survey_known_answers():
+    """SURVEY.md 8(c) known answers observed from the reference's own functions."""
+    A = orc.reference_input(12)
+    assert A[0, 0] == 99.857629722888433 and A[1, 0] == -0.099557382955938856
+    assert A[11, 11] == 100.17602371499687
+    A = orc.reference_input(1024)
+    assert A[0, 0] == 258.1900214764047 and A[1023, 1023] == 252.03312899746763
+    assert np.array_equal(np.load(os.path.join(GOLD, "spd_N12.npy")), orc.reference_input(12))
+
+
+def test_upper_variant():
+    assert sha(orc.make_spd_like_chameleon(12, uplo="U")) == G["upper_N12_sha"]
+
+
+def test_ragged_edge_tile_is_zero_padded():
+    A = orc.reference_input(10)
+    t = orc.extract_block(A, 4, 2, 2)
+    assert np.array_equal(t[:2, :2], A[8:, 8:]) and not t[2:, :].any() and not t[:, 2:].any()
+    assert orc.dpotrf(t)[1] == 3  # the padded block is singular: first bad pivot is row 3
+
+
+def test_reference_build_agrees_when_present():
+    try:
+        ref = orc.RefClient()
+    except FileNotFoundError:
+        pytest.skip("/root/reference not mounted (GPU box): covered by the golden vectors")
+    for N in (7, 12, 100, 333):
+        a, r = orc.reference_input(N), ref.reference_input(N)
+        assert np.array_equal(a.view(np.uint64), r.view(np.uint64))
+        B = 5
+        for bi in range((N + B - 1) // B):
+            assert np.array_equal(orc.extract_block(a, B, bi, 0), ref.extract_block(r, B, bi, 0))
+
+
+def test_tile_ops_against_openblas_fixture():
+    g = np.load(os.path.join(GOLD, "tileops_B64.npz"))
+    tol = 16 * 64 * np.finfo(float).eps
+    L, info = orc.dpotrf(g["Akk"])
+    assert info == 0 and np.abs(np.tril(L) - np.tril(g["potrf_out"])).max() <= tol * np.abs(g["potrf_out"]).max()
+    assert np.array_equal(np.triu(L, 1), np.triu(g["Akk"], 1))  # strict upper untouched
+    X10 = orc.dtrsm(g["potrf_out"], g["A10"])
+    assert np.abs(X10 - g["trsm10_out"]).max() <= tol
+    X20 = orc.dtrsm(g["potrf_out"], g["A20"])
+    assert np.abs(X20 - g["trsm20_out"]).max() <= tol
+    C11 = orc.dsyrk(g["trsm10_out"], g["A11"])
+    assert np.abs(np.tril(C11) - np.tril(g["syrk11_out"])).max() <= tol * np.abs(g["syrk11_out"]).max()
+    assert np.array_equal(np.triu(C11, 1), np.triu(g["A11"], 1))
+    C21 = orc.dgemm(g["trsm20_out"], g["trsm10_out"], g["A21"])
+    assert np.abs(C21 - g["gemm21_out"]).max() <= tol
+
+
+def test_trsm_ignores_upper_triangle_of_L():
+    rng = np.random.default_rng(1)
+    L = np.asfortranarray(np.tril(rng.standard_normal((32, 32))) + 6 * np.eye(32))
+    junk = L + np.triu(rng.standard_normal((32, 32)), 1)
+    X = np.asfortranarray(rng.standard_normal((32, 32)))
+    assert np.array_equal(orc.dtrsm(L, X), orc.dtrsm(junk, X))
+    assert np.abs(orc.dtrsm(L, X) @ L.T - X).max() < 1e-12
+
+
+def test_dag_against_fixtures():
+    g12 = np.load(os.path.join(GOLD, "dag_N12_B4.npz"))
+    L, info = orc.cholesky_lower(orc.reference_input(12), 4)
+    assert info == 0 and np.abs(L - g12["L"]).max() <= 1e-13
+    g = np.load(os.path.join(GOLD, "dag_N1024_B256.npz"))
+    A = orc.reference_input(1024)
+    L, info = orc.cholesky_lower(A, 256)
+    assert info == 0
+    assert np.abs(np.diag(L) - g["diag"]).max() <= 1e-12
+    assert np.abs(L[g["probe_i"], g["probe_j"]] - g["probe_v"]).max() <= 1e-12
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-13
+    assert orc.residual_lower(L, A) <= 1e-13
+
+
+def test_info_is_global_index():
+    A = orc.reference_input(64)
+    A[37, 37] = -1.0
+    assert orc.cholesky_lower(A, 16)[1] == 38
+
+
+def test_plgsy_generator_properties():
+    T = orc.plgsy_tiles(4, 8, 32.0, 42)
+    A = orc.tile_to_lapack(T, 32, 8)
+    assert np.array_equal(A, A.T)
+    off = A - np.diag(np.diag(A))
+    assert off.min() >= -0.5 and off.max() < 0.5 and np.diag(A).min() > 31.0
+    assert A[3, 17] == orc.plgsy_entry(32.0, 42, 3, 17) == orc.plgsy_entry(32.0, 42, 17, 3)
+    # independent of the tile size
+    assert np.array_equal(orc.tile_to_lapack(orc.plgsy_tiles(2, 16, 32.0, 42), 32, 16), A)
+
+
+def test_fp32_ops_match_fp64_to_single_precision():
+    rng = np.random.default_rng(5)
+    n = 48
+    M = rng.standard_normal((n, n))
+    S = np.asfortranarray(M @ M.T + n * np.eye(n))
+    L32, info = orc.spotrf(S.astype(np.float32))
+    assert info == 0 and np.abs(np.tril(L32) - np.linalg.cholesky(S)).max() < 1e-4
+    X = np.asfortranarray(rng.standard_normal((n, n)))
+    assert np.abs(orc.strsm(np.linalg.cholesky(S), X) - orc.dtrsm(np.linalg.cholesky(S), X)).max() < 1e-4
+    C0 = np.asfortranarray(rng.standard_normal((n, n)))
+    assert np.abs(orc.sgemm(X, M, C0) - orc.dgemm(X, M, C0)).max() < 1e-3
+    assert np.abs(np.tril(orc.ssyrk(X, C0)) - np.tril(orc.dsyrk(X, C0))).max() < 1e-3
