@@ -191,6 +191,13 @@ def last_potrf_stats() -> dict:
     return {"total_ms": t.value, "update_ms": u.value, "update_launches": n.value, "update_flops": f.value}
 
 
+def mfma_probe(dtype: int = ChamRealDouble, waves_per_simd: int = 1) -> float:
+    """TFLOP/s of a register-only MFMA stream on every CU (sustained matrix-core ceiling)."""
+    r = C.c_double()
+    check("chol_mfma_probe", lib().chol_mfma_probe(dtype, waves_per_simd, C.byref(r)))
+    return r.value
+
+
 def set_profiling(on: bool) -> None:
     lib().chol_set_profiling(1 if on else 0)
 

@@ -670,6 +670,35 @@ int chol_set_profiling(int on) {
   return 0;
 }
 
+int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "mfma_probe before chol_init");
+  if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(-2, "mfma_probe: arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, g.device));
+  const int blocks = prop.multiProcessorCount * waves_per_simd, iters = 4000;
+  int rc = ensure_stage(0, (size_t)blocks * 256 * sizeof(double));
+  if (rc) return rc;
+  rc = ensure_events(2);
+  if (rc) return rc;
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHECK(hipEventRecord(g.events[0], g.s_main));
+    if (dtype == CHOL_REAL_DOUBLE)
+      launch_mfma_probe<double>(g.s_main, (double *)g.stage[0], blocks, iters);
+    else
+      launch_mfma_probe<float>(g.s_main, (float *)g.stage[0], blocks, iters);
+    HIPCHECK(hipEventRecord(g.events[1], g.s_main));
+    HIPCHECK(hipStreamSynchronize(g.s_main));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, g.events[0], g.events[1]));
+    const double fl = (double)blocks * 4 * iters * 16 * 2048.0;
+    if (rep > 0) best = std::max(best, fl / (ms * 1e-3) / 1e12);
+  }
+  *tflops = best;
+  return 0;
+}
+
 // ---------------------------------------------------------------- distributed building blocks
 int chol_get_info(int *info) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "get_info before chol_init");
@@ -686,7 +715,7 @@ int chol_reset_info(void) {
 int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_potrf before chol_init");
   if (!d || !lkk) return fail(-1, "wave_potrf: NULL");
-  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
     launch_potrf_tile<double>(s, (double *)lkk, d->mb, (double *)g.winv, g.d_info, k * d->mb);
   else
@@ -698,7 +727,7 @@ int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
 int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_invert_diag before chol_init");
   if (!d || !lkk) return fail(-1, "wave_invert_diag: NULL");
-  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
     launch_invert_diag<double>(s, (const double *)lkk, d->mb, (double *)g.winv);
   else
@@ -711,7 +740,7 @@ int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_trsm before chol_init");
   if (!d || !lkk) return fail(-1, "wave_trsm: NULL");
   if (k % d->q != d->pcol) return 0;  // this process column holds no tile of panel k
-  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  hipStream_t s = (hipStream_t)stream;
   const int il0 = (k + d->p - d->prow) / d->p;  // first local row with global index > k
   const int cnt = d->lmt - il0;
   if (cnt <= 0) return 0;
@@ -733,7 +762,7 @@ int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const 
   if (jlo <= k) jlo = k + 1;
   if (jhi > d->nt) jhi = d->nt;
   if (jlo >= jhi) return 0;
-  hipStream_t s = stream ? (hipStream_t)stream : g.s_main;
+  hipStream_t s = (hipStream_t)stream;
   PanelRef pan;
   memset(&pan, 0, sizeof pan);
   pan.P = d->p;

@@ -267,64 +267,195 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A
 }
 
 // ------------------------------------------------------------------------------
-// 128 x 128 diagonal block: unblocked lower Cholesky in LDS (right-looking, one
-// column per step) followed by the in-place inverse of the triangular factor
-// (LAPACK dtrti2 'L' order), one workgroup.  factor = 0: only invert an already
-// factored block.  Strict upper triangle of A is never read or written.
+// 128 x 128 diagonal block: lower Cholesky and the inverse of the triangular factor,
+// one 256-thread workgroup, the block resident in LDS.
+//
+// Blocked by 16 columns.  Per 16-column panel:
+//   phase A (waves 0,1; registers + v_readlane, no LDS traffic, no barriers): each
+//     wave factors the 16x16 diagonal block held one row per lane (lanes 0-15) and, in
+//     the same sweep, solves its own 64 rows below it (one row per lane) against the
+//     factor -- every L(c,jj) is broadcast once through an SGPR and feeds three FMAs:
+//     the diagonal block's own update, the rows below, and the forward substitution
+//     that builds the diagonal block's inverse (wave 0, one column per lane);
+//   phase B (all waves): trailing update of the 16x16 blocks below/right with the
+//     16x16x4 MFMA straight out of LDS.
+// Then the inverse of the whole factor, in place over the strictly-lower blocks
+// (block version of LAPACK dtrti2 'L': block columns from the last to the first, the
+// untouched strictly-upper blocks serve as scratch), again on the MFMA.
+// factor = 0: only invert an already factored block.  The strict upper triangle of A
+// is never read or written.
 // ------------------------------------------------------------------------------
+__device__ __forceinline__ double rlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float rlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// acc(D layout) += First(16x16) * Second(16x16); element (i,k) of First at F[i*fi + k*fk],
+// element (k,j) of Second at Sd[k*sk + j*sj].  Lane l ends up with D[drow(l,reg)][l & 15].
+template <typename T>
+__device__ __forceinline__ void mm16(typename Tr<T>::acc_t &acc, const T *F, int fi, int fk,
+                                     const T *Sd, int sk, int sj, bool negate) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    T f = F[lo * fi + (4 * q + hi) * fk];
+    const T g = Sd[(4 * q + hi) * sk + lo * sj];
+    if (negate) f = -f;
+    acc = Tr<T>::mfma(f, g, acc);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
                                                     int info_base, int factor) {
-  constexpr int n = MACRO, LS = MACRO + 1;
+  constexpr int n = MACRO, LS = MACRO + 1, NB = 16, NP = MACRO / 16;
   __shared__ T S[n * LS];
-  __shared__ T col[n];
-  const int t = threadIdx.x;
+  __shared__ T Wd[NP][NB * NB];
+  __shared__ int failed;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
   for (int idx = t; idx < n * n; idx += 256) {
     const int i = idx & (n - 1), j = idx >> 7;
     S[i + j * LS] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
   }
+  if (t == 0) failed = 0;
   __syncthreads();
+
   if (factor) {
-    const int i = t & (n - 1), half = t >> 7;
-    for (int j = 0; j < n; ++j) {
-      T d = S[j + j * LS];
-      if (!(d > T(0))) {  // non-positive or NaN pivot: LAPACK info = j (1-based)
-        if (t == 0) atomicCAS(info, 0, info_base + j + 1);
-        return;
+    for (int p = 0; p < NP; ++p) {
+      const int j0 = NB * p;
+      // ---- phase A
+      if (w == 0 || (w == 1 && j0 + NB + 64 < n)) {
+        T dd[NB], a[NB], x[NB];
+        const int drow = j0 + lo;
+        const int myrow = j0 + NB + 64 * w + lane;
+        const bool rowok = myrow < n;
+        const int rr = rowok ? myrow : n - 1;
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+          dd[jj] = S[drow + (j0 + jj) * LS];
+          a[jj] = S[rr + (j0 + jj) * LS];
+          x[jj] = (lo == jj) ? T(1) : T(0);
+        }
+        int bad = 0;
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+          const T d = rlane(dd[jj], jj);
+          if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
+          const T sq = sqrt(d);
+          const T rinv = T(1) / sq;
+          dd[jj] = (lo == jj) ? sq : dd[jj] * rinv;
+          a[jj] *= rinv;
+          x[jj] *= rinv;
+#pragma unroll
+          for (int c = jj + 1; c < NB; ++c) {
+            const T l = rlane(dd[jj], c);  // L(c, jj)
+            dd[c] -= dd[jj] * l;
+            a[c] -= a[jj] * l;
+            x[c] -= x[jj] * l;
+          }
+        }
+        if (bad) {
+          if (w == 0 && lane == 0) {
+            atomicCAS(info, 0, info_base + j0 + bad);
+            failed = 1;
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj) {
+            if (rowok) S[myrow + (j0 + jj) * LS] = a[jj];
+            if (w == 0 && lane < NB) {
+              if (jj <= lane) S[drow + (j0 + jj) * LS] = dd[jj];
+              Wd[p][jj + lane * NB] = x[jj];  // column `lane` of the inverse, exact zeros above
+            }
+          }
+        }
       }
-      d = sqrt(d);
-      const T rinv = T(1) / d;
-      __syncthreads();  // everyone has read the pivot
-      if (t == j) S[j + j * LS] = d;
-      if (t > j && t < n) S[t + j * LS] *= rinv;
       __syncthreads();
-      if (i > j) {
-        const T lij = S[i + j * LS];
-        for (int c = j + 1 + half; c <= i; c += 2) S[i + c * LS] -= lij * S[c + j * LS];
-      }
+      if (failed) return;
+      // ---- phase B: S(r,c) -= X(r,p) X(c,p)^T for 16x16 blocks p < c <= r
+      int bidx = 0;
+      for (int c = p + 1; c < NP; ++c)
+        for (int r = c; r < NP; ++r, ++bidx) {
+          if ((bidx & 3) != w) continue;
+          typename Tr<T>::acc_t acc;
+          T *Cb = S + NB * r + (NB * c) * LS;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[reg] = Cb[Tr<T>::drow(lane, reg) + lo * LS];
+          // D[i][j] = sum_k X(r)[i][k] * X(c)[j][k]
+          mm16<T>(acc, S + NB * r + j0 * LS, 1, LS, S + NB * c + j0 * LS, LS, 1, true);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
+        }
       __syncthreads();
     }
     for (int idx = t; idx < n * n; idx += 256) {
-      const int i2 = idx & (n - 1), j2 = idx >> 7;
-      if (i2 >= j2) A[i2 + (size_t)j2 * ld] = S[i2 + j2 * LS];
+      const int i = idx & (n - 1), j = idx >> 7;
+      if (i >= j) A[i + (size_t)j * ld] = S[i + j * LS];
+    }
+  } else {
+    // inverses of the 16x16 diagonal blocks of an already factored block
+    for (int p = w; p < NP; p += 4) {
+      const int j0 = NB * p;
+      T dd[NB], x[NB];
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        dd[jj] = S[j0 + lo + (j0 + jj) * LS];
+        x[jj] = (lo == jj) ? T(1) : T(0);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        const T rinv = T(1) / rlane(dd[jj], jj);
+        x[jj] *= rinv;
+#pragma unroll
+        for (int c = jj + 1; c < NB; ++c) x[c] -= x[jj] * rlane(dd[jj], c);
+      }
+      if (lane < NB) {
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
+      }
     }
   }
-  // in-place inverse of the lower-triangular factor
-  for (int j = n - 1; j >= 0; --j) {
-    const T ajj = T(1) / S[j + j * LS];
-    if (t > j && t < n) col[t] = S[t + j * LS];
-    __syncthreads();
-    if (t > j && t < n) {
-      T sum = T(0);
-      for (int k = j + 1; k <= t; ++k) sum += S[t + k * LS] * col[k];
-      S[t + j * LS] = -ajj * sum;
+  __syncthreads();
+
+  // ---- inverse of the whole factor, block column j from NP-2 down to 0:
+  //   Y(i) = sum_{k=j+1..i} W(i,k) L(k,j)   -> scratch block (j,i) above the diagonal
+  //   W(i,j) = -Y(i) W(j,j)                  -> overwrites L(i,j)
+  for (int j = NP - 2; j >= 0; --j) {
+    for (int i = j + 1 + w; i < NP; i += 4) {
+      typename Tr<T>::acc_t acc;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
+      for (int k = j + 1; k < i; ++k)
+        mm16<T>(acc, S + NB * i + (NB * k) * LS, 1, LS, S + NB * k + (NB * j) * LS, 1, LS, false);
+      mm16<T>(acc, Wd[i], 1, NB, S + NB * i + (NB * j) * LS, 1, LS, false);
+      T *Y = S + NB * j + (NB * i) * LS;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Y[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
     }
-    if (t == j) S[j + j * LS] = ajj;
+    __syncthreads();
+    for (int i = j + 1 + w; i < NP; i += 4) {
+      typename Tr<T>::acc_t acc;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
+      mm16<T>(acc, S + NB * j + (NB * i) * LS, 1, LS, Wd[j], 1, NB, true);
+      T *Wb = S + NB * i + (NB * j) * LS;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
+    }
     __syncthreads();
   }
   for (int idx = t; idx < n * n; idx += 256) {
-    const int i2 = idx & (n - 1), j2 = idx >> 7;
-    winv[idx] = (i2 >= j2) ? S[i2 + j2 * LS] : T(0);
+    const int i = idx & (n - 1), j = idx >> 7;
+    T v = T(0);
+    if ((i >> 4) == (j >> 4))
+      v = Wd[i >> 4][(i & 15) + (j & 15) * NB];
+    else if (i > j)
+      v = S[i + j * LS];
+    winv[idx] = v;
   }
 }
 
@@ -508,6 +639,42 @@ template <typename T>
 void launch_pad_identity(hipStream_t s, T *dst, int n, int ldp) {
   if (ldp > n) k_pad_identity<T><<<(ldp - n + 127) / 128, 128, 0, s>>>(dst, n, ldp);
 }
+
+
+// ------------------------------------------------------------------------------
+// MFMA issue-rate probe: register-only 16x16x4 MFMA stream, 16 independent
+// accumulators per wave, operands random-looking.  Gives the matrix-core ceiling this
+// chip actually sustains (clock under load) beside the datasheet peak.
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(T *out, int iters) {
+  typename Tr<T>::acc_t acc[16];
+  const int t = threadIdx.x + blockIdx.x * 256;
+  T a = T((t * 2654435761u >> 8) & 0xffff) * T(1.0 / 65536) - T(0.5);
+  T b = T((t * 40503u >> 4) & 0xffff) * T(1.0 / 65536) - T(0.5);
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[u][r] = T(u + r);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = Tr<T>::mfma(a, b, acc[u]);
+    a = -a;  // keep the sums bounded
+  }
+  T s = T(0);
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += acc[u][r];
+  out[t] = s;
+}
+
+template <typename T>
+void launch_mfma_probe(hipStream_t s, T *out, int blocks, int iters) {
+  k_mfma_probe<T><<<blocks, 256, 0, s>>>(out, iters);
+}
+template void launch_mfma_probe<double>(hipStream_t, double *, int, int);
+template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int,       \

@@ -98,7 +98,11 @@ class HipEngine:
         return self.torch.cuda.Stream(device=self.dev, priority=-1)
 
     def main_stream(self):
-        return self.torch.cuda.current_stream(self.dev)
+        # a stream of our own: torch's default stream is the HIP null stream, which would
+        # serialise against every other stream of the process
+        if getattr(self, "_main", None) is None:
+            self._main = self.torch.cuda.Stream(device=self.dev)
+        return self._main
 
     def stream_ctx(self, s):
         return self.torch.cuda.stream(s)
@@ -215,7 +219,8 @@ class BlockCyclicCholesky:
                 e.update(k, k + 2, e.nt, bases, firsts, main)
             else:
                 e.update(k, k + 1, e.nt, bases, firsts, main)
-                panel = self._panel(k + 1, main)
+                with e.stream_ctx(main):
+                    panel = self._panel(k + 1, main)
         e.wait(main, side)
         e.synchronize()
         info = e.info()

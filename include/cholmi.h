@@ -144,10 +144,14 @@ int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launc
  * the streams; for bench.py's roofline leg only), 0 = off (default). */
 int chol_set_profiling(int on);
 
+/* Register-only 16x16x4 MFMA stream on every CU (waves_per_simd = 1..8): the matrix-core
+ * rate this chip sustains under load, to quote beside the datasheet peak. */
+int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);
+
 /* ---- distributed (one process per GPU) building blocks -------------------- */
 /* Used by the Python driver that moves panel tiles with torch.distributed
  * (RCCL).  All are asynchronous on the stream passed as `stream` (a hipStream_t
- * cast to void*; NULL = the library's main stream).  `k` is the wave index. */
+ * cast to void*; NULL = the HIP null stream).  `k` is the wave index. */
 void *chol_desc_local_ptr(chol_desc_t *desc, size_t *bytes);
 int chol_desc_local_tiles(chol_desc_t *desc, int *lmt, int *lnt);
 /* POTRF of tile (k,k) in place (owner only) and its 128-block inverses into the
