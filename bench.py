@@ -46,7 +46,8 @@ def cpu_baseline(N: int, B: int, seed: int) -> dict:
     timed on this box's host cores on a bounded sample: one factorisation at (N, B)."""
     from oracle import oracle as orc
 
-    nthreads = orc.num_threads()
+    # the GPU box's CPU share for one GPU is 16 cores; never more threads than that
+    nthreads = min(orc.num_threads(), len(os.sched_getaffinity(0)), int(os.environ.get("CHOLMI_CPU_THREADS", "16")))
     T = orc.plgsy_tiles(N // B, B, float(N), seed)
     t0 = time.perf_counter()
     info = orc.tiled_potrf(T, N // B, B, nthreads)
