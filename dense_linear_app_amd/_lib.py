@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
         "chol_last_potrf_stats": ([C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(d)], i),
         "chol_set_profiling": ([i], i),
         "chol_mfma_probe": ([i, i, C.POINTER(d)], i),
+        "chol_bench_update": ([vp, i, i, i, C.POINTER(d), C.POINTER(d)], i),
         "chol_desc_local_ptr": ([vp, C.POINTER(C.c_size_t)], vp),
         "chol_desc_local_tiles": ([vp, C.POINTER(i), C.POINTER(i)], i),
         "chol_wave_potrf": ([vp, i, vp, vp], i),

@@ -198,6 +198,13 @@ def mfma_probe(dtype: int = ChamRealDouble, waves_per_simd: int = 1) -> float:
     return r.value
 
 
+def bench_update(desc: Desc, k: int = 0, ablate: int = 0, reps: int = 3) -> tuple[float, float]:
+    """(ms, TFLOP/s) of wave k's trailing-update launch alone (diagnostic; modifies the matrix)."""
+    ms, fl = C.c_double(), C.c_double()
+    check("chol_bench_update", lib().chol_bench_update(desc.handle, k, ablate, reps, C.byref(ms), C.byref(fl)))
+    return ms.value, fl.value / (ms.value * 1e-3) / 1e12
+
+
 def set_profiling(on: bool) -> None:
     lib().chol_set_profiling(1 if on else 0)
 

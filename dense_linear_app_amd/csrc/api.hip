@@ -388,6 +388,7 @@ int chol_init(int ncpu, int ngpu) {
   HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_main, hipStreamNonBlocking, lo));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
+  if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
@@ -667,6 +668,40 @@ int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launc
 
 int chol_set_profiling(int on) {
   g.profiling = on != 0;
+  return 0;
+}
+
+int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, double *flops) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "bench_update before chol_init");
+  if (!d || !ms || d->p * d->q != 1 || !d->on_device || d->mt != d->nt || k < 0 || k + 1 >= d->nt || reps < 1)
+    return fail(-1, "bench_update: arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = ensure_events(2);
+  if (rc) return rc;
+  PanelRef pan;
+  memset(&pan, 0, sizeof pan);
+  pan.P = 1;
+  pan.base[0] = (char *)d->mat + (size_t)k * d->nt * d->bsiz * d->esize;
+  const LocalMat C = local_mat(d, d->mat);
+  const int ntiles = d->ge[k + 1];
+  cholmi::g_ablate = ablate;
+  float best = 1e30f;
+  for (int r = 0; r <= reps; ++r) {
+    HIPCHECK(hipEventRecord(g.events[0], g.s_main));
+    if (d->dtype == CHOL_REAL_DOUBLE)
+      launch_trail_update<double>(g.s_main, C, d->d_list, 0, ntiles, pan);
+    else
+      launch_trail_update<float>(g.s_main, C, d->d_list, 0, ntiles, pan);
+    HIPCHECK(hipEventRecord(g.events[1], g.s_main));
+    HIPCHECK(hipStreamSynchronize(g.s_main));
+    float t = 0;
+    HIPCHECK(hipEventElapsedTime(&t, g.events[0], g.events[1]));
+    if (r > 0 && t < best) best = t;
+  }
+  cholmi::g_ablate = 0;
+  *ms = best;
+  const double ntl = (double)(d->nt - 1 - k);
+  if (flops) *flops = (ntl * (ntl - 1) + ntl) * (double)d->mb * d->mb * d->mb;
   return 0;
 }
 

@@ -29,6 +29,9 @@ struct LocalMat {
   long bsiz; // elements per tile
 };
 
+extern int g_ablate;
+extern int g_variant;
+
 // ---- launchers (kernels.hip) ---------------------------------------------
 // C(i,j) -= L(i,k) L(j,k)^T for the `ntiles` (i,j) pairs in d_list[off .. off+ntiles)
 template <typename T>

@@ -55,7 +55,7 @@ constexpr int BK = 16;
 constexpr int LROW = MACRO + 16;
 
 template <typename T>
-struct Smem {
+struct alignas(16) Smem {
   T a[2][BK][LROW];
   T b[2][BK][LROW];
 };
@@ -79,7 +79,7 @@ __device__ __forceinline__ void acc_zero(Acc<T> &acc) {
 template <typename T, bool MASKA, bool MASKB>
 __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const T *__restrict__ B,
                                          int ldb, int K, Acc<T> &acc, Smem<T> &sm, int amask,
-                                         int bmask) {
+                                         int bmask, int ablate = 0) {
   using vec_t = typename Tr<T>::vec_t;
   constexpr int EPV = Tr<T>::EPV;
   constexpr int TPC = MACRO / EPV;  // threads per k-column
@@ -121,45 +121,255 @@ __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk && !(ablate & 1)) gload((kt + 1) * BK);
+    T af[4], bf[4];
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      T af[4], bf[4];
       const int kk = ks * 4 + (lane >> 4);
+      if (!(ablate & 2) || (kt == 0 && ks == 0)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = sm.a[cur][kk][wr * 64 + a * 16 + (lane & 15)];
+        for (int a = 0; a < 4; ++a) af[a] = sm.a[cur][kk][wr * 64 + a * 16 + (lane & 15)];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = sm.b[cur][kk][wc * 64 + b * 16 + (lane & 15)];
+        for (int b = 0; b < 4; ++b) bf[b] = sm.b[cur][kk][wc * 64 + b * 16 + (lane & 15)];
+      }
+      // stage the next slice into the other LDS buffer under the last MFMA group, so
+      // that nothing but the barrier itself is left at the end of the slice
+      if (ks == BK / 4 - 1 && kt + 1 < nk) lstore(cur ^ 1);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = Tr<T>::mfma(bf[b], af[a], acc[a][b]);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+    if (!(ablate & 8)) __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------
+// "Paired" form of the NT core (trailing update): fragment rows are interleaved so that
+// lane i of a 16-lane group owns EPL = 16 B / sizeof(T) CONSECUTIVE rows (fp64: rows 2i,
+// 2i+1 of a 32-row group; fp32: rows 4i..4i+3 of the 64-row group).  One ds_read_b128
+// then delivers the operand element of EPL MFMA tiles at once (half / quarter the LDS
+// instructions), the k-row stride is exactly 128 elements (no padding: the four 16-lane
+// groups of a b128 read cover the 64 banks once), and in the epilogue every lane reads
+// and writes 16 contiguous bytes of C (256 B contiguous per 16 lanes).
+// acc[a][b] <-> rows  64*wr + (a/EPL)*16*EPL + EPL*(lane&15) + a%EPL
+//               cols  64*wc + (b/EPL)*16*EPL + EPL*drow(lane,reg) + b%EPL
+// ------------------------------------------------------------------------------
+template <typename T>
+struct alignas(16) SmemP {
+  T a[2][BK][MACRO];
+  T b[2][BK][MACRO];
+};
+
+template <typename T, bool DMA>
+__device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda,
+                                                const T *__restrict__ B, int ldb, int K, Acc<T> &acc,
+                                                SmemP<T> &sm) {
+  using vec_t = typename Tr<T>::vec_t;
+  constexpr int EPV = Tr<T>::EPV;  // elements per 16 bytes == EPL
+  constexpr int NG = 4 / EPV;      // 16-lane row groups per 64 rows: fp64 2, fp32 1
+  constexpr int TPC = MACRO / EPV;
+  constexpr int CPP = 256 / TPC;
+  constexpr int NP = BK / CPP;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+  const int lrow = (t % TPC) * EPV, lcol = t / TPC;
+  vec_t ra[NP], rb[NP];
+  const T *Ag = A + lrow + (size_t)lcol * lda;
+  const T *Bg = B + lrow + (size_t)lcol * ldb;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      ra[p] = *reinterpret_cast<const vec_t *>(Ag + (size_t)(k0 + p * CPP) * lda);
+      rb[p] = *reinterpret_cast<const vec_t *>(Bg + (size_t)(k0 + p * CPP) * ldb);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<vec_t *>(&sm.a[buf][p * CPP + lcol][lrow]) = ra[p];
+      *reinterpret_cast<vec_t *>(&sm.b[buf][p * CPP + lcol][lrow]) = rb[p];
+    }
+  };
+  // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction moves one 1 KiB piece
+  // (64 lanes x 16 B) straight into the LDS image at a wave-uniform base -- no staging
+  // registers, no ds_write.  Piece q of a slice = bytes [q KiB, (q+1) KiB) of the
+  // [BK][128] image; wave w moves pieces w, w+4, ...
+  constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024;  // per operand per slice
+  constexpr int EPP = 1024 / (int)sizeof(T);                  // elements per piece
+  auto dma = [&](int buf, int k0) {
+#pragma unroll
+    for (int q = 0; q < PIECES / 4; ++q) {
+      const int piece = q * 4 + w;
+      const int e = piece * EPP + lane * EPV;  // element index inside the slice image
+      const int kk = e / MACRO, r = e % MACRO;
+      T *la = &sm.a[buf][0][0] + piece * EPP;
+      T *lb = &sm.b[buf][0][0] + piece * EPP;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
+          (__attribute__((address_space(3))) void *)la, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+          (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
+    }
+  };
+  vec_t fa[2][NG], fb[2][NG];
+  const int arow = wr * 64 + EPV * (lane & 15), brow = wc * 64 + EPV * (lane & 15), kq = lane >> 4;
+  auto fread = [&](int set, int cur, int ks) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      fa[set][g] = *reinterpret_cast<const vec_t *>(&sm.a[cur][ks * 4 + kq][arow + g * 16 * EPV]);
+      fb[set][g] = *reinterpret_cast<const vec_t *>(&sm.b[cur][ks * 4 + kq][brow + g * 16 * EPV]);
+    }
+  };
+
+  if (DMA) {
+    dma(0, 0);
+  } else {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    fread(0, cur, 0);
+    if (kt + 1 < nk) {
+      if (DMA)
+        dma(cur ^ 1, (kt + 1) * BK);
+      else
+        gload((kt + 1) * BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      if (ks + 1 < BK / 4)
+        fread((ks + 1) & 1, cur, ks + 1);
+      else if (!DMA && kt + 1 < nk)
+        lstore(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = Tr<T>::mfma(fb[ks & 1][b / EPV][b % EPV], fa[ks & 1][a / EPV][a % EPV], acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
   }
 }
 
-// C(128x128 block) := alpha*acc + beta*C ; lower: keep only (moff + m >= noff + n)
-template <typename T>
-__device__ __forceinline__ void nt_epilogue(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
-                                            T beta, bool lower, int moff, int noff) {
+template <typename T, bool LOWER>
+__device__ __forceinline__ void nt_epilogue_paired_impl(T *__restrict__ C, int ldc, Acc<T> &acc,
+                                                        T alpha, T beta) {
+  using vec_t = typename Tr<T>::vec_t;
+  constexpr int EPV = Tr<T>::EPV, NG = 4 / EPV;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+  const int m0 = wr * 64 + EPV * (lane & 15);
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < 4; ++b) {
+    vec_t cv[4][NG];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 64 + (b / EPV) * 16 * EPV + EPV * Tr<T>::drow(lane, r) + b % EPV;
+      const T *col = C + (size_t)n * ldc + m0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (beta != T(0)) cv[r][g] = *reinterpret_cast<const vec_t *>(col + g * 16 * EPV);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const T v = alpha * acc[g * EPV + e][b][r];
+          cv[r][g][e] = (beta != T(0)) ? v + beta * cv[r][g][e] : v;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 64 + (b / EPV) * 16 * EPV + EPV * Tr<T>::drow(lane, r) + b % EPV;
+      T *col = C + (size_t)n * ldc + m0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int m = m0 + g * 16 * EPV;
+        if (!LOWER || m >= n) {  // all EPV rows at or below the diagonal
+          *reinterpret_cast<vec_t *>(col + g * 16 * EPV) = cv[r][g];
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e)
+            if (m + e >= n) col[g * 16 * EPV + e] = cv[r][g][e];
+        }
+      }
+    }
+  }
+}
+
+// C(128x128 block) := alpha*acc + beta*C ; LOWER: store only elements with m >= n
+// (diagonal blocks of SYRK-type updates).  The C tile is read in four batches of 16
+// loads per lane (all issued before the first use), then written: four memory round
+// trips per workgroup instead of one per element.
+template <typename T, bool LOWER>
+__device__ __forceinline__ void nt_epilogue_impl(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
+                                                 T beta) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
+  const int m0 = wr * 64 + (lane & 15);
+  if (beta == T(0)) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+        T *col = C + (size_t)n * ldc;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int m = m0 + a * 16;
+          if (!LOWER || m >= n) col[m] = alpha * acc[a][b][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    T cv[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+      const T *col = C + (size_t)n * ldc;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cv[r][a] = col[m0 + a * 16];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cv[r][a] = alpha * acc[a][b][r] + beta * cv[r][a];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+      T *col = C + (size_t)n * ldc;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int m = wr * 64 + a * 16 + (lane & 15);
-        if (lower && (moff + m < noff + n)) continue;
-        T *p = C + m + (size_t)n * ldc;
-        T v = alpha * acc[a][b][r];
-        if (beta != T(0)) v += beta * (*p);
-        *p = v;
+        const int m = m0 + a * 16;
+        if (!LOWER || m >= n) col[m] = cv[r][a];
       }
     }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void nt_epilogue(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
+                                            T beta, bool lower, int, int) {
+  if (lower)
+    nt_epilogue_impl<T, true>(C, ldc, acc, alpha, beta);
+  else
+    nt_epilogue_impl<T, false>(C, ldc, acc, alpha, beta);
+}
+
+template <typename T>
+__device__ __forceinline__ void nt_epilogue_paired(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
+                                                   T beta, bool lower) {
+  if (lower)
+    nt_epilogue_paired_impl<T, true>(C, ldc, acc, alpha, beta);
+  else
+    nt_epilogue_paired_impl<T, false>(C, ldc, acc, alpha, beta);
 }
 
 template <typename T>
@@ -178,8 +388,8 @@ __device__ __forceinline__ const T *panel_tile(const PanelRef &pan, int i, long 
 // fetched from HBM once per XCD.
 // ------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
-                                                         int ntiles, PanelRef pan, int nbm, int G) {
+__global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const int2 *__restrict__ list,
+                                                         int ntiles, PanelRef pan, int nbm, int G, int ablate) {
   __shared__ Smem<T> sm;
   const int MT = nbm * nbm;
   const int b = blockIdx.x, x = b & 7, s = b >> 3;
@@ -196,8 +406,34 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
           mi * MACRO + (long)mj * MACRO * C.mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop<T, false, false>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, 0, 0);
-  nt_epilogue<T>(Cp, C.mb, acc, T(-1), T(1), diag && mi == mj, 0, 0);
+  nt_kloop<T, false, false>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, 0, 0, ablate);
+  nt_epilogue<T>(Cp, C.mb, acc, T(-1), (ablate & 4) ? T(0) : T(1), diag && mi == mj, 0, 0);
+}
+
+template <typename T, bool DMA>
+__global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
+                                                           int ntiles, PanelRef pan, int nbm, int G) {
+  __shared__ SmemP<T> sm;
+  const int MT = nbm * nbm;
+  const int b = blockIdx.x, x = b & 7, s = b >> 3;
+  const int sg = s / MT, macro = s - sg * MT;
+  const int t = (sg / G) * (8 * G) + x * G + (sg % G);
+  if (t >= ntiles) return;
+  const int2 ij = list[t];
+  const int mi = macro % nbm, mj = macro / nbm;
+  const bool diag = (ij.x == ij.y);
+  if (diag && mi < mj) return;
+  const T *Ap = panel_tile<T>(pan, ij.x, C.bsiz) + mi * MACRO;
+  const T *Bp = panel_tile<T>(pan, ij.y, C.bsiz) + mj * MACRO;
+  T *Cp = reinterpret_cast<T *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
+          mi * MACRO + (long)mj * MACRO * C.mb;
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm);
+  if (diag && mi == mj)
+    nt_epilogue_paired_impl<T, true>(Cp, C.mb, acc, T(-1), T(1));
+  else
+    nt_epilogue_paired_impl<T, false>(Cp, C.mb, acc, T(-1), T(1));
 }
 
 // X[:, s] := alpha * A[:, s] * Winv_s^T, in place, for row blocks r >= r0 of `ntiles`
@@ -205,22 +441,22 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int mb, int nbm, int r0,
                                                         int s, const T *__restrict__ winv, T alpha) {
-  __shared__ Smem<T> sm;
+  __shared__ SmemP<T> sm;
   const int nr = nbm - r0;
   const int tix = blockIdx.x / nr, r = r0 + blockIdx.x % nr;
   T *Ap = tiles + (long)tix * bsiz + r * MACRO + (long)s * MACRO * mb;
   const T *Bp = winv + (long)s * MACRO * MACRO;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop<T, false, false>(Ap, mb, Bp, MACRO, MACRO, acc, sm, 0, 0);
-  nt_epilogue<T>(Ap, mb, acc, alpha, T(0), false, 0, 0);
+  nt_kloop_paired<T, true>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
+  nt_epilogue_paired<T>(Ap, mb, acc, alpha, T(0), false);
 }
 
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, int mb, int nbm, int s,
                                                          const T *__restrict__ lkk, T beta) {
-  __shared__ Smem<T> sm;
+  __shared__ SmemP<T> sm;
   const int nc = nbm - 1 - s;
   int b = blockIdx.x;
   const int c = s + 1 + b % nc;
@@ -232,14 +468,14 @@ __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, in
   T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop<T, false, false>(Ap, mb, Bp, mb, MACRO, acc, sm, 0, 0);
-  nt_epilogue<T>(Cp, mb, acc, T(-1), beta, false, 0, 0);
+  nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
+  nt_epilogue_paired<T>(Cp, mb, acc, T(-1), beta, false);
 }
 
 // in-tile trailing update of the blocked POTRF: C[r,c] -= X[r,s] X[c,s]^T, r >= c > s
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s) {
-  __shared__ Smem<T> sm;
+  __shared__ SmemP<T> sm;
   const int r = s + 1 + blockIdx.x, c = s + 1 + blockIdx.y;
   if (c > r) return;
   const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
@@ -247,8 +483,8 @@ __global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int n
   T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop<T, false, false>(Ap, mb, Bp, mb, MACRO, acc, sm, 0, 0);
-  nt_epilogue<T>(Cp, mb, acc, T(-1), T(1), r == c, 0, 0);
+  nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
+  nt_epilogue_paired<T>(Cp, mb, acc, T(-1), T(1), r == c);
 }
 
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
@@ -256,14 +492,14 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A,
                                                          const T *__restrict__ B, T *C, int mb,
                                                          int nbm, T alpha, T beta, int lower) {
-  __shared__ Smem<T> sm;
+  __shared__ SmemP<T> sm;
   const int mi = blockIdx.x, mj = blockIdx.y;
   if (lower && mi < mj) return;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop<T, false, false>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm, 0, 0);
-  nt_epilogue<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta,
-                 lower && mi == mj, 0, 0);
+  nt_kloop_paired<T, true>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
+  nt_epilogue_paired<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta,
+                 lower && mi == mj);
 }
 
 // ------------------------------------------------------------------------------
@@ -563,6 +799,9 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------
+int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
+int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
+
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int ntiles,
                          const PanelRef &pan) {
@@ -572,7 +811,13 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   if (G < 1) G = 1;
   const int ngroups = (ntiles + 8 * G - 1) / (8 * G);
   const long blocks = (long)ngroups * 8 * G * MT;
-  k_trail_update<T><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
+    k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G, g_ablate & 255);
+  else if (g_variant == 1)
+    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
+  else
+    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
 }
 
 template <typename T>

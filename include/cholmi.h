@@ -144,6 +144,11 @@ int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launc
  * the streams; for bench.py's roofline leg only), 0 = off (default). */
 int chol_set_profiling(int on);
 
+/* Diagnostic: time the trailing-update launch of wave k alone (best of `reps`), on whatever
+ * data the descriptor holds (the matrix is modified).  ablate: 0 = the production kernel; bit
+ * 0 no global loads, 1 no LDS fragment reads, 2 no C read, 3 no barriers (timing only). */
+int chol_bench_update(chol_desc_t *desc, int k, int ablate, int reps, double *ms, double *flops);
+
 /* Register-only 16x16x4 MFMA stream on every CU (waves_per_simd = 1..8): the matrix-core
  * rate this chip sustains under load, to quote beside the datasheet peak. */
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);

@@ -30,12 +30,17 @@ def run(N, B, reps=3, dtype=None, check=True):
 
 if __name__ == "__main__":
     ch.CHAMELEON_Init(1, 1)
-    for w in (1, 2):
+    for w in ((1, 2) if os.environ.get("PROBE_QUICK") != "1" else ()):
         print(f"mfma probe f64 waves/simd={w}: {ch.mfma_probe(ch.ChamRealDouble, w):.2f} TF/s ; f32: {ch.mfma_probe(ch.ChamRealFloat, w):.2f} TF/s", flush=True)
     cfgs = [(4096, 512), (16384, 512), (16384, 1024), (32768, 1024)]
     if len(sys.argv) > 1:
         cfgs = [tuple(map(int, a.split("x"))) for a in sys.argv[1:]]
+    quick = os.environ.get("PROBE_QUICK") == "1"
     for N, B in cfgs:
+        if quick:
+            ch.set_profiling(False)
+            run(N, B, reps=0, check=False)
+            continue
         ch.set_profiling(False)
         run(N, B, reps=2, check=(N <= 16384))
         ch.set_profiling(True)
