@@ -124,8 +124,14 @@ def run_multi(a) -> dict:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # rehearsal hook: CHOLMI_DIST_BACKEND=gloo lets several ranks share the GPUs that exist
+    backend = os.environ.get("CHOLMI_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
     chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)

@@ -545,17 +545,30 @@ __device__ __forceinline__ void mm16(typename Tr<T>::acc_t &acc, const T *F, int
   }
 }
 
+// LDS image of the diagonal block: only the 36 lower 16x16 blocks, each column-major with
+// leading dimension 17 (272 elements per block): 77 KiB instead of 129 KiB, so the kernel
+// fits on a CU beside one resident trailing-update workgroup (64 KiB) instead of waiting
+// for a whole CU to drain.  ld = 17 keeps row reads, column reads and MFMA fragment
+// reads of a block free of bank conflicts.
+constexpr int DB_LD = 17, DB_SZ = 16 * DB_LD, DB_NP = MACRO / 16;
+__device__ __forceinline__ int db_off(int r, int c) {  // block (r >= c)
+  return (c * DB_NP - (c * (c - 1)) / 2 + (r - c)) * DB_SZ;
+}
+__device__ __forceinline__ int db_idx(int i, int j) {  // element (i,j), block row >= block col
+  return db_off(i >> 4, j >> 4) + (i & 15) + (j & 15) * DB_LD;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
                                                     int info_base, int factor) {
-  constexpr int n = MACRO, LS = MACRO + 1, NB = 16, NP = MACRO / 16;
-  __shared__ T S[n * LS];
+  constexpr int n = MACRO, NB = 16, NP = DB_NP, NBLK = NP * (NP + 1) / 2;
+  __shared__ T S[NBLK * DB_SZ];
   __shared__ T Wd[NP][NB * NB];
   __shared__ int failed;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
   for (int idx = t; idx < n * n; idx += 256) {
     const int i = idx & (n - 1), j = idx >> 7;
-    S[i + j * LS] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
+    if ((i >> 4) >= (j >> 4)) S[db_idx(i, j)] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
   }
   if (t == 0) failed = 0;
   __syncthreads();
@@ -566,14 +579,15 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
       // ---- phase A
       if (w == 0 || (w == 1 && j0 + NB + 64 < n)) {
         T dd[NB], a[NB], x[NB];
-        const int drow = j0 + lo;
         const int myrow = j0 + NB + 64 * w + lane;
         const bool rowok = myrow < n;
         const int rr = rowok ? myrow : n - 1;
+        const T *Dp = S + db_off(p, p) + lo;
+        T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
-          dd[jj] = S[drow + (j0 + jj) * LS];
-          a[jj] = S[rr + (j0 + jj) * LS];
+          dd[jj] = Dp[jj * DB_LD];
+          a[jj] = Rp[jj * DB_LD];
           x[jj] = (lo == jj) ? T(1) : T(0);
         }
         int bad = 0;
@@ -600,11 +614,12 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
             failed = 1;
           }
         } else {
+          T *Dw = S + db_off(p, p) + lo;
 #pragma unroll
           for (int jj = 0; jj < NB; ++jj) {
-            if (rowok) S[myrow + (j0 + jj) * LS] = a[jj];
+            if (rowok) Rp[jj * DB_LD] = a[jj];
             if (w == 0 && lane < NB) {
-              if (jj <= lane) S[drow + (j0 + jj) * LS] = dd[jj];
+              if (jj <= lane) Dw[jj * DB_LD] = dd[jj];
               Wd[p][jj + lane * NB] = x[jj];  // column `lane` of the inverse, exact zeros above
             }
           }
@@ -618,28 +633,28 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
         for (int r = c; r < NP; ++r, ++bidx) {
           if ((bidx & 3) != w) continue;
           typename Tr<T>::acc_t acc;
-          T *Cb = S + NB * r + (NB * c) * LS;
+          T *Cb = S + db_off(r, c);
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) acc[reg] = Cb[Tr<T>::drow(lane, reg) + lo * LS];
+          for (int reg = 0; reg < 4; ++reg) acc[reg] = Cb[Tr<T>::drow(lane, reg) + lo * DB_LD];
           // D[i][j] = sum_k X(r)[i][k] * X(c)[j][k]
-          mm16<T>(acc, S + NB * r + j0 * LS, 1, LS, S + NB * c + j0 * LS, LS, 1, true);
+          mm16<T>(acc, S + db_off(r, p), 1, DB_LD, S + db_off(c, p), DB_LD, 1, true);
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
+          for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[reg];
         }
       __syncthreads();
     }
     for (int idx = t; idx < n * n; idx += 256) {
       const int i = idx & (n - 1), j = idx >> 7;
-      if (i >= j) A[i + (size_t)j * ld] = S[i + j * LS];
+      if (i >= j) A[i + (size_t)j * ld] = S[db_idx(i, j)];
     }
   } else {
     // inverses of the 16x16 diagonal blocks of an already factored block
     for (int p = w; p < NP; p += 4) {
-      const int j0 = NB * p;
       T dd[NB], x[NB];
+      const T *Dp = S + db_off(p, p) + lo;
 #pragma unroll
       for (int jj = 0; jj < NB; ++jj) {
-        dd[jj] = S[j0 + lo + (j0 + jj) * LS];
+        dd[jj] = Dp[jj * DB_LD];
         x[jj] = (lo == jj) ? T(1) : T(0);
       }
 #pragma unroll
@@ -657,30 +672,37 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
   }
   __syncthreads();
 
-  // ---- inverse of the whole factor, block column j from NP-2 down to 0:
-  //   Y(i) = sum_{k=j+1..i} W(i,k) L(k,j)   -> scratch block (j,i) above the diagonal
-  //   W(i,j) = -Y(i) W(j,j)                  -> overwrites L(i,j)
+  // ---- inverse of the whole factor, block column j from NP-2 down to 0 (in place):
+  //   Y(i) = sum_{k=j+1..i} W(i,k) L(k,j)   (kept in registers until every wave has read L(:,j))
+  //   W(i,j) = -Y(i) W(j,j)                  (overwrites L(i,j))
   for (int j = NP - 2; j >= 0; --j) {
-    for (int i = j + 1 + w; i < NP; i += 4) {
-      typename Tr<T>::acc_t acc;
+    typename Tr<T>::acc_t y[2];
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
-      for (int k = j + 1; k < i; ++k)
-        mm16<T>(acc, S + NB * i + (NB * k) * LS, 1, LS, S + NB * k + (NB * j) * LS, 1, LS, false);
-      mm16<T>(acc, Wd[i], 1, NB, S + NB * i + (NB * j) * LS, 1, LS, false);
-      T *Y = S + NB * j + (NB * i) * LS;
+    for (int u = 0; u < 2; ++u) {
+      const int i = j + 1 + w + 4 * u;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Y[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
+      for (int reg = 0; reg < 4; ++reg) y[u][reg] = T(0);
+      if (i < NP) {
+        for (int k = j + 1; k < i; ++k)
+          mm16<T>(y[u], S + db_off(i, k), 1, DB_LD, S + db_off(k, j), 1, DB_LD, false);
+        mm16<T>(y[u], Wd[i], 1, NB, S + db_off(i, j), 1, DB_LD, false);
+      }
     }
     __syncthreads();
-    for (int i = j + 1 + w; i < NP; i += 4) {
-      typename Tr<T>::acc_t acc;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
-      mm16<T>(acc, S + NB * j + (NB * i) * LS, 1, LS, Wd[j], 1, NB, true);
-      T *Wb = S + NB * i + (NB * j) * LS;
+    for (int u = 0; u < 2; ++u) {
+      const int i = j + 1 + w + 4 * u;
+      if (i < NP) {
+        T *Wb = S + db_off(i, j);
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * LS] = acc[reg];
+        for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * DB_LD] = y[u][reg];
+        typename Tr<T>::acc_t acc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
+        mm16<T>(acc, Wb, 1, DB_LD, Wd[j], 1, NB, true);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[reg];
+      }
     }
     __syncthreads();
   }
@@ -690,7 +712,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
     if ((i >> 4) == (j >> 4))
       v = Wd[i >> 4][(i & 15) + (j & 15) * NB];
     else if (i > j)
-      v = S[i + j * LS];
+      v = S[db_idx(i, j)];
     winv[idx] = v;
   }
 }
