@@ -146,10 +146,20 @@ class HipEngine:
 
 
 class BlockCyclicCholesky:
-    """The distributed wave loop.  `dist` is torch.distributed (already initialised)."""
+    """The distributed wave loop.  `dist` is torch.distributed (already initialised).
 
-    def __init__(self, engine, dist, lookahead: bool = True):
+    panel_mode "bcast": each of the P owners of panel k broadcasts its part to all ranks.
+    panel_mode "allgather": each owner scatters its part over its process row (Q chunks over Q
+    distinct links), then ONE world all-gather replicates the panel -- every link carries 1/8
+    of the panel instead of a ring carrying all of it.  Same result, same panel addressing.
+    """
+
+    def __init__(self, engine, dist, lookahead: bool = True, panel_mode: Optional[str] = None):
+        import os
+
         self.e, self.dist, self.lookahead = engine, dist, lookahead
+        self.panel_mode = panel_mode or os.environ.get("CHOLMI_PANEL_MODE", "bcast")
+        assert self.panel_mode in ("bcast", "allgather")
         e = engine
         self.world = dist.get_world_size()
         assert self.world == e.P * e.Q and dist.get_rank() == e.rank
@@ -159,34 +169,55 @@ class BlockCyclicCholesky:
             ranks = [pr * e.Q + qc for pr in range(e.P)]
             self.col_groups.append(dist.new_group(ranks=ranks) if e.P > 1 else None)
         maxpart = (e.nt + e.P - 1) // e.P
-        # receive buffers: [parity][process row]
-        self.pbuf = [[e.empty_tiles(maxpart) for _ in range(e.P)] for _ in range(2)]
         self.lkk_buf = [e.empty_tiles(1) for _ in range(2)]
+        if self.panel_mode == "bcast":
+            # receive buffers: [parity][process row]
+            self.pbuf = [[e.empty_tiles(maxpart) for _ in range(e.P)] for _ in range(2)]
+        else:
+            self.row_groups = []
+            for pr in range(e.P):
+                ranks = [pr * e.Q + qc for qc in range(e.Q)]
+                self.row_groups.append(dist.new_group(ranks=ranks) if e.Q > 1 else None)
+            self.chunkmax = (maxpart + e.Q - 1) // e.Q
+            self.gbuf = [e.empty_tiles(self.world * self.chunkmax) for _ in range(2)]
+            self.cbuf = [e.empty_tiles(self.chunkmax) for _ in range(2)]
+            self.tail = [e.empty_tiles(self.chunkmax) for _ in range(2)]
 
-    # -- one panel: POTRF(k,k), its broadcast down the process column, TRSMs, panel broadcast
-    def _panel(self, k: int, s):
+    # -- L(k,k): POTRF on its owner, broadcast down the process column, TRSM of the local panel tiles
+    def _diag_and_trsm(self, k: int, s) -> None:
         e, dist = self.e, self.dist
         P, Q = e.P, e.Q
         pr, pc = k % P, k % Q
         par = k & 1
-        in_col = (e.pcol == pc)
-        lkk = None
-        if in_col:
-            if e.prow == pr:
-                lkk = e.tiles_view(k // P, k // Q)
-                e.potrf(k, lkk, s)
-            else:
-                lkk = self.lkk_buf[par]
-            if P > 1 and k + 1 < e.nt:
-                dist.broadcast(lkk, src=pr * Q + pc, group=self.col_groups[pc])
-                if e.prow != pr:
-                    e.invert_diag(lkk, s)
-            if k + 1 < e.nt:
-                e.trsm(k, lkk, s)
+        if e.pcol != pc:
+            return
+        if e.prow == pr:
+            lkk = e.tiles_view(k // P, k // Q)
+            e.potrf(k, lkk, s)
+        else:
+            lkk = self.lkk_buf[par]
+        if P > 1 and k + 1 < e.nt:
+            dist.broadcast(lkk, src=pr * Q + pc, group=self.col_groups[pc])
+            if e.prow != pr:
+                e.invert_diag(lkk, s)
+        if k + 1 < e.nt:
+            e.trsm(k, lkk, s)
+
+    def _part(self, k: int, p2: int):
+        """(first local row, tile count) of the part of panel k owned by process row p2."""
+        e = self.e
+        il0 = first_local_row_above(k, p2, e.P)
+        return il0, max(0, (e.nt - p2 + e.P - 1) // e.P - il0)
+
+    # -- one panel, mode "bcast"
+    def _panel_bcast(self, k: int, s):
+        e, dist = self.e, self.dist
+        P, Q = e.P, e.Q
+        pc, par = k % Q, k & 1
+        self._diag_and_trsm(k, s)
         bases, firsts = [], []
         for p2 in range(P):
-            il0 = first_local_row_above(k, p2, P)
-            cnt = max(0, (e.nt - p2 + P - 1) // P - il0)
+            il0, cnt = self._part(k, p2)
             src = p2 * Q + pc
             if e.rank == src:
                 buf = e.tiles_view(il0, k // Q, cnt) if cnt > 0 else self.pbuf[par][p2][:0]
@@ -197,6 +228,53 @@ class BlockCyclicCholesky:
             bases.append(buf if cnt > 0 else self.pbuf[par][p2])
             firsts.append(il0)
         return bases, firsts
+
+    # -- one panel, mode "allgather"
+    def _panel_allgather(self, k: int, s):
+        e, dist = self.e, self.dist
+        P, Q, bs = e.P, e.Q, e.bsiz
+        pc, par = k % Q, k & 1
+        self._diag_and_trsm(k, s)
+        parts = [self._part(k, p2) for p2 in range(P)]
+        chunk = max((cnt + Q - 1) // Q for _, cnt in parts)
+        gbuf, cbuf, tail = self.gbuf[par], self.cbuf[par], self.tail[par]
+        firsts = [il0 for il0, _ in parts]
+        bases = [gbuf[p2 * Q * chunk * bs:] if chunk > 0 else gbuf for p2 in range(P)]
+        if chunk == 0:
+            return bases, firsts
+        # step 1: the owner of my process row's part scatters it over the row
+        il0, cnt = parts[e.prow]
+        src = e.prow * Q + pc
+        mine = cbuf[:chunk * bs]
+        views = None
+        if e.rank == src:
+            part = e.tiles_view(il0, k // Q, cnt) if cnt > 0 else tail[:0]
+            views = []
+            for q in range(Q):
+                lo, hi = min(cnt, q * chunk), min(cnt, (q + 1) * chunk)
+                if hi - lo == chunk:
+                    views.append(part[lo * bs:hi * bs])
+                else:
+                    if hi > lo:  # the one ragged chunk: stage it so the send stays in bounds
+                        tail[:(hi - lo) * bs].copy_(part[lo * bs:hi * bs])
+                    views.append(tail[:chunk * bs])
+        if Q > 1:
+            dist.scatter(mine, views, src=src, group=self.row_groups[e.prow])
+        else:
+            mine.copy_(views[0])
+        # step 2: one world all-gather replicates the panel; rank r's chunk lands at r*chunk
+        out = gbuf[:self.world * chunk * bs]
+        if self.world > 1:
+            try:
+                dist.all_gather_into_tensor(out, mine)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                dist.all_gather([out[r * chunk * bs:(r + 1) * chunk * bs] for r in range(self.world)], mine)
+        else:
+            out.copy_(mine)
+        return bases, firsts
+
+    def _panel(self, k: int, s):
+        return self._panel_bcast(k, s) if self.panel_mode == "bcast" else self._panel_allgather(k, s)
 
     def factorize(self) -> int:
         """In place on the engine's tiles.  Returns LAPACK info (max over ranks)."""

@@ -20,7 +20,7 @@ def run(N, B, reps=3, dtype=None, check=True):
         st = ch.last_potrf_stats()
         if r > 0:
             best = min(best, dt)
-        print(f"N={N} B={B} rep={r} info={info} wall={dt*1e3:.2f} ms dev={st['total_ms']:.2f} ms "
+        print(f"N={N} B={B} {'f32' if dtype == ch.ChamRealFloat else 'f64'} rep={r} info={info} wall={dt*1e3:.2f} ms dev={st['total_ms']:.2f} ms "
               f"{N**3/3/dt/1e12:.2f} TF/s  upd_ms={st['update_ms']:.2f} upd_tf={st['update_flops']/max(st['update_ms'],1e-9)/1e9:.2f}", flush=True)
     if check:
         print("  residual", ch.residual_plgsy(d, float(N), 42), flush=True)
@@ -34,14 +34,16 @@ if __name__ == "__main__":
         print(f"mfma probe f64 waves/simd={w}: {ch.mfma_probe(ch.ChamRealDouble, w):.2f} TF/s ; f32: {ch.mfma_probe(ch.ChamRealFloat, w):.2f} TF/s", flush=True)
     cfgs = [(4096, 512), (16384, 512), (16384, 1024), (32768, 1024)]
     if len(sys.argv) > 1:
-        cfgs = [tuple(map(int, a.split("x"))) for a in sys.argv[1:]]
+        cfgs = [tuple(a.split("x")) for a in sys.argv[1:]]
     quick = os.environ.get("PROBE_QUICK") == "1"
-    for N, B in cfgs:
+    for cfg in cfgs:
+        N, B = int(cfg[0]), int(cfg[1])
+        dt = ch.ChamRealFloat if len(cfg) > 2 and cfg[2] == "f32" else ch.ChamRealDouble
         if quick:
             ch.set_profiling(False)
-            run(N, B, reps=0, check=False)
+            run(N, B, reps=0, dtype=dt, check=False)
             continue
         ch.set_profiling(False)
-        run(N, B, reps=2, check=(N <= 16384))
+        run(N, B, reps=2, dtype=dt, check=(N <= 16384))
         ch.set_profiling(True)
-        run(N, B, reps=1, check=False)
+        run(N, B, reps=1, dtype=dt, check=False)

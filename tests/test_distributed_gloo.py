@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, B, lookahead, bad, q):
+def _worker(rank, world, port, N, B, lookahead, bad, q, mode="bcast"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,7 +41,7 @@ def _worker(rank, world, port, N, B, lookahead, bad, q):
             t = eng.download_tile(I, I)
             t[bad % B, bad % B] = -3.0
             eng.upload_tile(I, I, t)
-    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=lookahead)
+    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=lookahead, panel_mode=mode)
     info = chol.factorize()
     tiles = {}
     for I in range(eng.nt):
@@ -53,11 +53,11 @@ def _worker(rank, world, port, N, B, lookahead, bad, q):
     dist.destroy_process_group()
 
 
-def _run(world, N, B, lookahead=True, bad=None):
+def _run(world, N, B, lookahead=True, bad=None, mode="bcast"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, lookahead, bad, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, lookahead, bad, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
@@ -67,12 +67,14 @@ def _run(world, N, B, lookahead=True, bad=None):
     return got
 
 
-@pytest.mark.parametrize("world,lookahead", [(2, True), (2, False), (4, True)])
-def test_block_cyclic_factorisation_matches_oracle(world, lookahead):
+@pytest.mark.parametrize("world,lookahead,mode", [(2, True, "bcast"), (2, False, "bcast"), (4, True, "bcast"),
+                                                  (2, True, "allgather"), (4, True, "allgather"),
+                                                  (4, False, "allgather")])
+def test_block_cyclic_factorisation_matches_oracle(world, lookahead, mode):
     from oracle import oracle as orc
 
-    N, B = 96, 16
-    got = _run(world, N, B, lookahead)
+    N, B = 112, 16  # 7 tiles per side: ragged parts and ragged chunks
+    got = _run(world, N, B, lookahead, mode=mode)
     T = orc.plgsy_tiles(N // B, B, float(N), 42)
     assert orc.tiled_potrf(T, N // B, B) == 0
     Lref = orc.tile_to_lapack(T, N, B)

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, B, dtype, q):
+def _worker(rank, world, port, N, B, dtype, q, mode):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, N, B, dtype, q):
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(N, B, P, Q, rank, dtype, device=0)
     eng.generate(float(N), 42)
-    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
+    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True, panel_mode=mode)
     info = chol.factorize()
     tiles = {}
     for I in range(eng.nt):
@@ -47,15 +47,15 @@ def _worker(rank, world, port, N, B, dtype, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_hip_engine_block_cyclic(world, orc):
+@pytest.mark.parametrize("world,mode", [(1, "bcast"), (2, "bcast"), (4, "bcast"), (2, "allgather"), (4, "allgather")])
+def test_hip_engine_block_cyclic(world, mode, orc):
     import torch.multiprocessing as mp
 
-    N, B = 2048, 256
+    N, B = 2304, 256  # 9 tiles per side: ragged parts and chunks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, "f64", q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, "f64", q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
