@@ -135,6 +135,7 @@ def run_multi(a) -> dict:
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
     chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
+    chol.warm_up()
     for w in range(a.warmup):
         eng.generate(float(a.N), a.seed)
         info = chol.factorize()

@@ -559,12 +559,19 @@ __device__ __forceinline__ int db_idx(int i, int j) {  // element (i,j), block r
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
-                                                    int info_base, int factor) {
-  constexpr int n = MACRO, NB = 16, NP = DB_NP, NBLK = NP * (NP + 1) / 2;
-  __shared__ T S[NBLK * DB_SZ];
-  __shared__ T Wd[NP][NB * NB];
-  __shared__ int failed;
+struct DiagLds {
+  T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
+  T Wd[DB_NP][16 * 16];
+  int failed;
+};
+
+template <typename T>
+__device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ winv, int *info,
+                                                int info_base, int factor, DiagLds<T> &L) {
+  constexpr int n = MACRO, NB = 16, NP = DB_NP;
+  T *S = L.S;
+  T(*Wd)[NB * NB] = L.Wd;
+  int &failed = L.failed;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
   for (int idx = t; idx < n * n; idx += 256) {
     const int i = idx & (n - 1), j = idx >> 7;
@@ -715,6 +722,13 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
       v = S[db_idx(i, j)];
     winv[idx] = v;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
+                                                    int info_base, int factor) {
+  __shared__ DiagLds<T> L;
+  potrf_diag_body<T>(A, ld, winv, info, info_base, factor, L);
 }
 
 // ------------------------------------------------------------------------------

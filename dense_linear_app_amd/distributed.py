@@ -183,6 +183,28 @@ class BlockCyclicCholesky:
             self.cbuf = [e.empty_tiles(self.chunkmax) for _ in range(2)]
             self.tail = [e.empty_tiles(self.chunkmax) for _ in range(2)]
 
+    def warm_up(self) -> None:
+        """Create every communicator this object will use (RCCL builds them lazily on first use)
+        outside any timed region: one tiny collective per group."""
+        e, dist = self.e, self.dist
+        if self.world == 1:
+            return
+        t = e.empty_tiles(1)[:8]
+        dist.broadcast(t, src=0)
+        if e.P > 1:
+            dist.broadcast(t, src=e.pcol, group=self.col_groups[e.pcol])
+        if self.panel_mode == "allgather":
+            if e.Q > 1:
+                src = e.prow * e.Q
+                dist.scatter(t, [t.clone() for _ in range(e.Q)] if e.rank == src else None, src=src,
+                             group=self.row_groups[e.prow])
+            out = e.empty_tiles(1)[:8 * self.world]
+            try:
+                dist.all_gather_into_tensor(out, t)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                dist.all_gather([out[r * 8:(r + 1) * 8] for r in range(self.world)], t)
+        e.synchronize()
+
     # -- L(k,k): POTRF on its owner, broadcast down the process column, TRSM of the local panel tiles
     def _diag_and_trsm(self, k: int, s) -> None:
         e, dist = self.e, self.dist

@@ -42,6 +42,7 @@ def _worker(rank, world, port, N, B, lookahead, bad, q, mode="bcast"):
             t[bad % B, bad % B] = -3.0
             eng.upload_tile(I, I, t)
     chol = dd.BlockCyclicCholesky(eng, dist, lookahead=lookahead, panel_mode=mode)
+    chol.warm_up()
     info = chol.factorize()
     tiles = {}
     for I in range(eng.nt):
