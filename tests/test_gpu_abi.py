@@ -1,0 +1,127 @@
+"""The C ABI's argument checking and descriptor semantics on the GPU box: LAPACK-style
+negative statuses for bad arguments, CHOL_ERR_NOT_SUPPORTED for valid-but-uncovered
+Chameleon usage (never a wrong answer), randomised shapes/scalars against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc(L, a, dt=3, **kw):
+    B = a.shape[0]
+    args = dict(mb=B, nb=B, bsiz=B * B, lm=B, ln=B, i=0, j=0, m=B, n=B, p=1, q=1)
+    args.update(kw)
+    h = C.c_void_p()
+    rc = L.chol_desc_create(C.byref(h), a.ctypes.data, dt, args["mb"], args["nb"], args["bsiz"], args["lm"],
+                            args["ln"], args["i"], args["j"], args["m"], args["n"], args["p"], args["q"])
+    return rc, h
+
+
+def test_desc_create_argument_positions(cham):
+    from dense_linear_app_amd._lib import lib
+
+    L = lib()
+    a = np.zeros((8, 8), order="F")
+    assert _desc(L, a)[0] == 0
+    assert _desc(L, a, dt=7)[0] == -3
+    assert _desc(L, a, mb=0)[0] == -4
+    assert _desc(L, a, nb=-1)[0] == -5
+    assert _desc(L, a, bsiz=63)[0] == -6
+    assert _desc(L, a, lm=0)[0] == -7
+    assert _desc(L, a, ln=0)[0] == -8
+    assert _desc(L, a, m=9)[0] == -11
+    assert _desc(L, a, n=9)[0] == -12
+    assert _desc(L, a, p=0)[0] == -13
+    assert _desc(L, a, q=0)[0] == -14
+    assert _desc(L, a, i=2, m=6)[0] == -104  # sub-matrix view: valid Chameleon, not covered
+    assert _desc(L, a, p=2)[0] == -104       # p*q must match the number of ranks
+    assert b"chol_set_rank" in L.chol_last_error()
+
+
+def test_ops_reject_null_and_mismatched_descriptors(cham):
+    from dense_linear_app_amd._lib import lib
+
+    ch, L = cham, lib()
+    a8, a16 = np.eye(8, order="F"), np.eye(16, order="F")
+    _, d8 = _desc(L, a8)
+    _, d16 = _desc(L, a16)
+    assert L.chol_potrf_tile(ch.ChamLower, None) == -2
+    assert L.chol_potrf_tile(999, d8) == -1
+    assert L.chol_trsm_tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, None, d8) == -6
+    assert L.chol_trsm_tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, d8, None) == -7
+    assert L.chol_trsm_tile(0, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, d8, d8) == -1
+    assert L.chol_trsm_tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, d8, d16) == -104
+    assert L.chol_syrk_tile(ch.ChamLower, ch.ChamNoTrans, -1.0, d8, 1.0, None) == -6
+    assert L.chol_syrk_tile(ch.ChamUpper, ch.ChamNoTrans, -1.0, d8, 1.0, d8) == -104
+    assert L.chol_gemm_tile(ch.ChamNoTrans, ch.ChamTrans, -1.0, d8, None, 1.0, d8) == -5
+    assert L.chol_gemm_tile(ch.ChamNoTrans, ch.ChamTrans, -1.0, d8, d16, 1.0, d8) == -104
+    f8 = np.eye(8, dtype=np.float32, order="F")
+    _, df = _desc(L, f8, dt=ch.ChamRealFloat)
+    assert L.chol_gemm_tile(ch.ChamNoTrans, ch.ChamTrans, -1.0, d8, df, 1.0, d8) == -104  # mixed types
+    for h in (d8, d16, df):
+        assert L.chol_desc_destroy(C.byref(h)) == 0
+    assert L.chol_desc_destroy(C.byref(C.c_void_p())) == -1
+
+
+def test_whole_matrix_descriptor_restrictions(cham):
+    ch = cham
+    with pytest.raises(ch.CholmiError, match="ragged"):
+        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 256, 256, 256 * 256, 1000, 1000, 0, 0, 1000, 1000, 1, 1)
+    with pytest.raises(ch.CholmiError, match="multiple of 128"):
+        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 200, 200, 200 * 200, 800, 800, 0, 0, 800, 800, 1, 1)
+    d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 256, 256, 256 * 256, 512, 1024, 0, 0, 512, 1024, 1, 1)
+    with pytest.raises(ch.CholmiError, match="not square"):
+        ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+
+
+def test_host_resident_tiled_matrix_is_staged(cham, orc):
+    """A multi-tile descriptor over a HOST buffer in tile layout: staged through HBM as a whole."""
+    ch = cham
+    N, B = 1024, 256
+    A = orc.reference_input(N)
+    T = orc.lapack_to_tile(A, B)
+    d = ch.CHAMELEON_Desc_Create(T, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(orc.tile_to_lapack(T, N, B))
+    Lref, _ = orc.cholesky_lower(A, B)
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-12
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(B=st.integers(1, 300), alpha=st.floats(-2, 2), beta=st.floats(-2, 2), seed=st.integers(0, 2 ** 31))
+def test_gemm_syrk_random_shapes_and_scalars(cham, orc, B, alpha, beta, seed):
+    ch = cham
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(rng.uniform(-1, 1, (B, B)))
+    Bm = np.asfortranarray(rng.uniform(-1, 1, (B, B)))
+    C0 = np.asfortranarray(rng.uniform(-1, 1, (B, B)))
+    mk = lambda a: ch.CHAMELEON_Desc_Create(a, ch.ChamRealDouble, B, B, B * B, B, B, 0, 0, B, B, 1, 1)
+    tol = 16 * max(B, 8) * np.finfo(float).eps * (abs(alpha) * B + abs(beta) + 1)
+    Cg = C0.copy(order="F")
+    assert ch.CHAMELEON_dgemm_Tile(ch.ChamNoTrans, ch.ChamTrans, alpha, mk(A), mk(Bm), beta, mk(Cg)) == 0
+    assert np.abs(Cg - orc.dgemm(A, Bm, C0, alpha, beta)).max() <= tol
+    Cs = C0.copy(order="F")
+    assert ch.CHAMELEON_dsyrk_Tile(ch.ChamLower, ch.ChamNoTrans, alpha, mk(A), beta, mk(Cs)) == 0
+    assert np.abs(np.tril(Cs) - np.tril(orc.dsyrk(A, C0, alpha, beta))).max() <= tol
+    assert np.array_equal(np.triu(Cs, 1), np.triu(C0, 1))
+
+
+@settings(max_examples=15, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(B=st.integers(1, 260), seed=st.integers(0, 2 ** 31))
+def test_potrf_trsm_random_spd(cham, orc, B, seed):
+    ch = cham
+    rng = np.random.default_rng(seed)
+    M = rng.uniform(-1, 1, (B, B))
+    S = np.asfortranarray(M @ M.T + B * np.eye(B))
+    mk = lambda a: ch.CHAMELEON_Desc_Create(a, ch.ChamRealDouble, B, B, B * B, B, B, 0, 0, B, B, 1, 1)
+    L = S.copy(order="F")
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, mk(L)) == 0
+    Lref = np.linalg.cholesky(S)
+    assert np.abs(np.tril(L) - Lref).max() <= 64 * max(B, 8) * np.finfo(float).eps * np.abs(Lref).max()
+    X = np.asfortranarray(rng.uniform(-1, 1, (B, B)))
+    X0 = X.copy()
+    assert ch.CHAMELEON_dtrsm_Tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, mk(L), mk(X)) == 0
+    assert np.abs(X @ Lref.T - X0).max() <= 256 * max(B, 8) * np.finfo(float).eps * max(1.0, np.abs(X).max()) * np.abs(Lref).max()
