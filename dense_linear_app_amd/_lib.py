@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         "chol_extract_block": ([vp, i, i, i, i, i, vp], None),
         "chol_last_potrf_stats": ([C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(d)], i),
         "chol_set_profiling": ([i], i),
+        "chol_debug_stamps": ([i, C.POINTER(C.c_ulonglong), i], i),
         "chol_mfma_probe": ([i, i, C.POINTER(d)], i),
         "chol_bench_update": ([vp, i, i, i, C.POINTER(d), C.POINTER(d)], i),
         "chol_desc_local_ptr": ([vp, C.POINTER(C.c_size_t)], vp),

@@ -705,6 +705,28 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   return 0;
 }
 
+int chol_debug_stamps(int enable, unsigned long long *out, int max_pairs) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "debug_stamps before chol_init");
+  static unsigned long long *buf = nullptr;
+  const size_t bytes = (1 + 8 * 1000) * sizeof(unsigned long long);
+  HIPCHECK(hipDeviceSynchronize());
+  if (enable) {
+    if (!buf) HIPCHECK(hipMalloc(&buf, bytes));
+    HIPCHECK(hipMemset(buf, 0, bytes));
+    cholmi::g_dbg = buf;
+    return 0;
+  }
+  int n = 0;
+  if (buf && out) {
+    std::vector<unsigned long long> h(1 + 8 * 1000);
+    HIPCHECK(hipMemcpy(h.data(), buf, bytes, hipMemcpyDeviceToHost));
+    n = (int)std::min<unsigned long long>(h[0], (unsigned long long)std::min(max_pairs, 1000));
+    memcpy(out, h.data() + 1, (size_t)n * 8 * sizeof(unsigned long long));
+  }
+  cholmi::g_dbg = nullptr;
+  return n;
+}
+
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "mfma_probe before chol_init");
   if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(-2, "mfma_probe: arguments");

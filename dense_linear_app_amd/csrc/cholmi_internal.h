@@ -31,6 +31,7 @@ struct LocalMat {
 
 extern int g_ablate;
 extern int g_variant;
+extern unsigned long long *g_dbg;
 
 // ---- launchers (kernels.hip) ---------------------------------------------
 // C(i,j) -= L(i,k) L(j,k)^T for the `ntiles` (i,j) pairs in d_list[off .. off+ntiles)

@@ -442,6 +442,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int mb, int nbm, int r0,
                                                         int s, const T *__restrict__ winv, T alpha) {
   __shared__ SmemP<T> sm;
+  __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nr = nbm - r0;
   const int tix = blockIdx.x / nr, r = r0 + blockIdx.x % nr;
   T *Ap = tiles + (long)tix * bsiz + r * MACRO + (long)s * MACRO * mb;
@@ -457,6 +458,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, int mb, int nbm, int s,
                                                          const T *__restrict__ lkk, T beta) {
   __shared__ SmemP<T> sm;
+  __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nc = nbm - 1 - s;
   int b = blockIdx.x;
   const int c = s + 1 + b % nc;
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, in
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s) {
   __shared__ SmemP<T> sm;
+  __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int r = s + 1 + blockIdx.x, c = s + 1 + blockIdx.y;
   if (c > r) return;
   const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
@@ -558,6 +561,29 @@ __device__ __forceinline__ int db_idx(int i, int j) {  // element (i,j), block r
   return db_off(i >> 4, j >> 4) + (i & 15) + (j & 15) * DB_LD;
 }
 
+// sqrt(d) and 1/sqrt(d) by v_rsq + two coupled Goldschmidt steps (~10 dependent fp64 ops
+// instead of the ~25 of IEEE sqrt followed by an IEEE divide).  The fp64 MFMA and the fp64
+// VALU share the SIMD's DP units, so beside a trailing update every dependent fp64
+// instruction of this kernel waits for a 64-cycle MFMA: the pivot chain is the critical path.
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &s, double &rinv) {
+  double r = __builtin_amdgcn_rsq(d);
+  double g = d * r, h = 0.5 * r;
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  // one correction step on the root itself: g += h * (d - g*g) * ... (h ~ 1/(2 sqrt d))
+  const double c = __builtin_fma(-g, g, d);
+  s = __builtin_fma(c, h, g);
+  rinv = h + h;
+}
+__device__ __forceinline__ void sqrt_rsqrt(float d, float &s, float &rinv) {
+  s = sqrtf(d);
+  rinv = 1.0f / s;
+}
+
 template <typename T>
 struct DiagLds {
   T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
@@ -567,25 +593,45 @@ struct DiagLds {
 
 template <typename T>
 __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ winv, int *info,
-                                                int info_base, int factor, DiagLds<T> &L) {
+                                                int info_base, int factor, DiagLds<T> &L,
+                                                unsigned long long *ph = nullptr) {
   constexpr int n = MACRO, NB = 16, NP = DB_NP;
+  unsigned long long tA = 0, tB = 0, tl = 0;
+#define PH_NOW() (ph ? __builtin_amdgcn_s_memrealtime() : 0ull)
   T *S = L.S;
   T(*Wd)[NB * NB] = L.Wd;
   int &failed = L.failed;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
-  for (int idx = t; idx < n * n; idx += 256) {
-    const int i = idx & (n - 1), j = idx >> 7;
-    if ((i >> 4) >= (j >> 4)) S[db_idx(i, j)] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
+  // Load the lower triangle: 16 independent loads in flight per thread and pass (the kernel
+  // usually runs beside a trailing update that keeps the memory system busy, where one
+  // dependent round trip per element cost 5x the whole factorisation).
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = t + 256 * (16 * pass + u);
+      const int i = idx & (n - 1), j = idx >> 7;
+      v[u] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = t + 256 * (16 * pass + u);
+      const int i = idx & (n - 1), j = idx >> 7;
+      if ((i >> 4) >= (j >> 4)) S[db_idx(i, j)] = v[u];
+    }
   }
   if (t == 0) failed = 0;
   __syncthreads();
+  if (ph && t == 0) ph[0] = PH_NOW();  // loaded
 
   if (factor) {
     for (int p = 0; p < NP; ++p) {
       const int j0 = NB * p;
+      tl = PH_NOW();
       // ---- phase A
       if (w == 0 || (w == 1 && j0 + NB + 64 < n)) {
-        T dd[NB], a[NB], x[NB];
+        T dd[NB], a[NB];
         const int myrow = j0 + NB + 64 * w + lane;
         const bool rowok = myrow < n;
         const int rr = rowok ? myrow : n - 1;
@@ -595,24 +641,21 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
         for (int jj = 0; jj < NB; ++jj) {
           dd[jj] = Dp[jj * DB_LD];
           a[jj] = Rp[jj * DB_LD];
-          x[jj] = (lo == jj) ? T(1) : T(0);
         }
         int bad = 0;
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
           const T d = rlane(dd[jj], jj);
           if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
-          const T sq = sqrt(d);
-          const T rinv = T(1) / sq;
+          T sq, rinv;
+          sqrt_rsqrt(d, sq, rinv);
           dd[jj] = (lo == jj) ? sq : dd[jj] * rinv;
           a[jj] *= rinv;
-          x[jj] *= rinv;
 #pragma unroll
           for (int c = jj + 1; c < NB; ++c) {
             const T l = rlane(dd[jj], c);  // L(c, jj)
             dd[c] -= dd[jj] * l;
             a[c] -= a[jj] * l;
-            x[c] -= x[jj] * l;
           }
         }
         if (bad) {
@@ -625,15 +668,14 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #pragma unroll
           for (int jj = 0; jj < NB; ++jj) {
             if (rowok) Rp[jj * DB_LD] = a[jj];
-            if (w == 0 && lane < NB) {
-              if (jj <= lane) Dw[jj * DB_LD] = dd[jj];
-              Wd[p][jj + lane * NB] = x[jj];  // column `lane` of the inverse, exact zeros above
-            }
+            if (w == 0 && lane < NB && jj <= lane) Dw[jj * DB_LD] = dd[jj];
           }
         }
       }
       __syncthreads();
       if (failed) return;
+      tA += PH_NOW() - tl;
+      tl = PH_NOW();
       // ---- phase B: S(r,c) -= X(r,p) X(c,p)^T for 16x16 blocks p < c <= r
       int bidx = 0;
       for (int c = p + 1; c < NP; ++c)
@@ -649,35 +691,42 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
           for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[reg];
         }
       __syncthreads();
+      tB += PH_NOW() - tl;
+    }
+    if (ph && t == 0) {
+      ph[1] = tA;
+      ph[2] = tB;
     }
     for (int idx = t; idx < n * n; idx += 256) {
       const int i = idx & (n - 1), j = idx >> 7;
       if (i >= j) A[i + (size_t)j * ld] = S[db_idx(i, j)];
     }
-  } else {
-    // inverses of the 16x16 diagonal blocks of an already factored block
-    for (int p = w; p < NP; p += 4) {
-      T dd[NB], x[NB];
-      const T *Dp = S + db_off(p, p) + lo;
+  }
+  if (ph && t == 0) ph[3] = PH_NOW();  // L stored
+  // inverses of the eight 16x16 diagonal blocks (one column per lane, forward substitution
+  // with L(c,jj) broadcast by v_readlane), two blocks per wave, all waves in parallel
+  for (int p = w; p < NP; p += 4) {
+    T dd[NB], x[NB];
+    const T *Dp = S + db_off(p, p) + lo;
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) {
-        dd[jj] = Dp[jj * DB_LD];
-        x[jj] = (lo == jj) ? T(1) : T(0);
-      }
+    for (int jj = 0; jj < NB; ++jj) {
+      dd[jj] = Dp[jj * DB_LD];
+      x[jj] = (lo == jj) ? T(1) : T(0);
+    }
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) {
-        const T rinv = T(1) / rlane(dd[jj], jj);
-        x[jj] *= rinv;
+    for (int jj = 0; jj < NB; ++jj) {
+      const T rinv = T(1) / rlane(dd[jj], jj);
+      x[jj] *= rinv;
 #pragma unroll
-        for (int c = jj + 1; c < NB; ++c) x[c] -= x[jj] * rlane(dd[jj], c);
-      }
-      if (lane < NB) {
+      for (int c = jj + 1; c < NB; ++c) x[c] -= x[jj] * rlane(dd[jj], c);
+    }
+    if (lane < NB) {
 #pragma unroll
-        for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
-      }
+      for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
     }
   }
   __syncthreads();
+  if (ph && t == 0) ph[4] = PH_NOW();  // Wd done
 
   // ---- inverse of the whole factor, block column j from NP-2 down to 0 (in place):
   //   Y(i) = sum_{k=j+1..i} W(i,k) L(k,j)   (kept in registers until every wave has read L(:,j))
@@ -713,6 +762,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
     }
     __syncthreads();
   }
+  if (ph && t == 0) ph[5] = PH_NOW();  // phase C done
+#undef PH_NOW
   for (int idx = t; idx < n * n; idx += 256) {
     const int i = idx & (n - 1), j = idx >> 7;
     T v = T(0);
@@ -724,11 +775,28 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   }
 }
 
+// dbg (diagnostic, may be null): dbg[0] = running slot counter, then per launch the
+// workgroup's own {start, end} in 100 MHz realtime ticks.
 template <typename T>
 __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
-                                                    int info_base, int factor) {
+                                                    int info_base, int factor,
+                                                    unsigned long long *dbg) {
   __shared__ DiagLds<T> L;
-  potrf_diag_body<T>(A, ld, winv, info, info_base, factor, L);
+  __shared__ unsigned long long slot_s;
+  __builtin_amdgcn_s_setprio(3);
+  unsigned long long t0 = 0;
+  unsigned long long *ph = nullptr;
+  if (dbg) {
+    t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) slot_s = atomicAdd(dbg, 1ull);
+    __syncthreads();
+    if (slot_s < 1000) ph = dbg + 1 + 8 * slot_s + 2;
+  }
+  potrf_diag_body<T>(A, ld, winv, info, info_base, factor, L, ph);
+  if (ph && threadIdx.x == 0) {
+    ph[-2] = t0;
+    ph[-1] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -835,6 +903,7 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------
+unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
@@ -861,7 +930,7 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
   const int nbm = mb / MACRO;
   for (int st = 0; st < nbm; ++st) {
     k_potrf_diag<T><<<1, 256, 0, s>>>(tile + (long)st * MACRO * (mb + 1), mb,
-                                      winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1);
+                                      winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1, g_dbg);
     const int nr = nbm - 1 - st;
     if (nr > 0) {
       k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1));
@@ -875,7 +944,7 @@ void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
   const int nbm = mb / MACRO;
   for (int st = 0; st < nbm; ++st)
     k_potrf_diag<T><<<1, 256, 0, s>>>(const_cast<T *>(tile) + (long)st * MACRO * (mb + 1), mb,
-                                      winv + (long)st * MACRO * MACRO, nullptr, 0, 0);
+                                      winv + (long)st * MACRO * MACRO, nullptr, 0, 0, nullptr);
 }
 
 template <typename T>

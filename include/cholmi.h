@@ -149,6 +149,12 @@ int chol_set_profiling(int on);
  * 0 no global loads, 1 no LDS fragment reads, 2 no C read, 3 no barriers (timing only). */
 int chol_bench_update(chol_desc_t *desc, int k, int ablate, int reps, double *ms, double *flops);
 
+/* Diagnostic: enable = 1 starts recording, per diagonal-block workgroup, 8 words of 100 MHz
+ * realtime ticks {start, end, loaded, sum phase A, sum phase B, L stored, block inverses done,
+ * factor inverse done}; enable = 0 stops, copies up to max_pairs records (8 words each) to
+ * `out` and returns their number. */
+int chol_debug_stamps(int enable, unsigned long long *out, int max_pairs);
+
 /* Register-only 16x16x4 MFMA stream on every CU (waves_per_simd = 1..8): the matrix-core
  * rate this chip sustains under load, to quote beside the datasheet peak. */
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);
