@@ -86,6 +86,34 @@ class ProcessStatus:
 ProcessStatus.Ok = ProcessStatus("", _ok=True)
 
 
+class DeviceBlob:
+    """A result that lives in HBM: same wire format (raw column-major doubles), different address
+    space.  With `ControlPlane(device_results=True)` tiles are uploaded once, every task's inputs
+    and output stay on the GPU, and only `download_result_data` copies back -- the MI355X answer
+    to the reference's per-task download/upload of every tile through the object store."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor  # 1-D torch tensor on the GPU (owns the memory)
+
+    @property
+    def nbytes(self) -> int:
+        return self.tensor.numel() * self.tensor.element_size()
+
+    def __len__(self) -> int:
+        return self.nbytes
+
+    @classmethod
+    def from_bytes(cls, data) -> "DeviceBlob":
+        import numpy as np
+        import torch
+
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        return cls(torch.from_numpy(a.copy()).cuda())
+
+    def to_bytes(self) -> bytes:
+        return self.tensor.cpu().numpy().tobytes()
+
+
 class ResultNotAvailable(RuntimeError):
     """wait_for_result_availability on a result that was aborted or can never be produced."""
 
@@ -109,6 +137,8 @@ class TaskHandler:
 
     def getPayload(self) -> str:
         data = self._plane._results[self._task.payload_id].data
+        if isinstance(data, DeviceBlob):
+            data = data.to_bytes()
         return bytes(data).decode("utf-8")
 
     def getExpectedResults(self) -> List[str]:
@@ -169,7 +199,8 @@ class _Task:
 class ControlPlane:
     """What stands between the four clients and the worker(s)."""
 
-    def __init__(self):
+    def __init__(self, device_results: bool = False):
+        self.device_results = device_results
         self._sessions: Dict[str, TaskOptions] = {}
         self._results: Dict[str, _Result] = {}
         self._tasks: Dict[str, _Task] = {}
@@ -189,7 +220,7 @@ class ControlPlane:
             raise KeyError(f"unknown result id {result_id}")
         if r.status == "completed":
             raise RuntimeError(f"result {result_id} is write-once and already has data")
-        r.data = bytes(data)
+        r.data = data if isinstance(data, DeviceBlob) else bytes(data)
         r.status = "completed"
 
     def _ready(self, t: _Task) -> bool:
@@ -275,6 +306,9 @@ class ResultsClient:
     def upload_result_data(self, session_id: str, result_id: str, data) -> None:
         if isinstance(data, str):
             data = data.encode("utf-8")
+        name = self._plane._results[result_id].name if result_id in self._plane._results else ""
+        if self._plane.device_results and name != "payload" and not isinstance(data, DeviceBlob):
+            data = DeviceBlob.from_bytes(data)  # tiles go to HBM once; payloads stay on the host
         self._plane._complete_result(result_id, data)
         self._plane._pump()
 
@@ -282,7 +316,7 @@ class ResultsClient:
         r = self._plane._results[result_id]
         if r.status != "completed":
             raise ResultNotAvailable(f"result {result_id} is {r.status}")
-        return r.data
+        return r.data.to_bytes() if isinstance(r.data, DeviceBlob) else r.data
 
 
 class TasksClient:

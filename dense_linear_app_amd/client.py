@@ -202,10 +202,12 @@ def default_task_options() -> ak.TaskOptions:
 
 
 def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, worker=None,
-                     A: Optional[np.ndarray] = None, verbose: bool = False, log=sys.stdout) -> DagResult:
-    """C2:325-568 (main) as a function.  `worker` defaults to DagCholeskyWorker on the GPU."""
+                     A: Optional[np.ndarray] = None, verbose: bool = False, log=sys.stdout,
+                     device_results: bool = False) -> DagResult:
+    """C2:325-568 (main) as a function.  `worker` defaults to DagCholeskyWorker on the GPU.
+    device_results=True keeps every tile version in HBM between tasks (armonik.DeviceBlob)."""
     if plane is None:
-        plane = ak.ControlPlane()
+        plane = ak.ControlPlane(device_results=device_results)
     if worker is None:
         from .worker import DagCholeskyWorker
 

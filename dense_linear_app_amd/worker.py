@@ -29,7 +29,7 @@ from typing import Optional
 import numpy as np
 
 from . import chameleon as ch
-from .armonik import ArmoniKWorker, ProcessStatus, TaskHandler
+from .armonik import ArmoniKWorker, DeviceBlob, ProcessStatus, TaskHandler
 
 
 @dataclass
@@ -116,8 +116,32 @@ class HipTileBackend:
             ch.CHAMELEON_Desc_Destroy(dAj)
 
 
-def _to_doubles(blob) -> np.ndarray:
-    """bytes -> std::vector<double> (full copy, W2:212-213); trailing partial doubles dropped."""
+class _DevTile:
+    """A private device copy of a tile blob (the worker mutates copies, W2:212-213)."""
+
+    def __init__(self, blob: DeviceBlob):
+        import torch
+
+        n = blob.nbytes // 8
+        self.t = blob.tensor.view(torch.uint8)[:n * 8].clone()
+        torch.cuda.current_stream().synchronize()  # libcholmi runs on its own (non-blocking) stream
+        self.size = n
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def tobytes(self) -> DeviceBlob:  # stays in HBM: the "bytes" of a device tile is the tile
+        return DeviceBlob(self.t)
+
+    def host(self) -> np.ndarray:
+        return np.frombuffer(self.t.cpu().numpy().tobytes(), dtype=np.float64)
+
+
+def _to_doubles(blob):
+    """bytes -> std::vector<double> (full copy, W2:212-213); trailing partial doubles dropped.
+    A DeviceBlob is copied device-to-device and never leaves HBM."""
+    if isinstance(blob, DeviceBlob):
+        return _DevTile(blob)
     n = len(blob) // 8
     return np.frombuffer(blob, dtype=np.float64, count=n).copy()
 
@@ -137,6 +161,7 @@ class DagCholeskyWorker(ArmoniKWorker):
             return
         parts = []
         for name, X in arrays.items():
+            X = X.host() if isinstance(X, _DevTile) else X
             parts.append(f"||{name}||F={np.linalg.norm(X):.6g} NaN/Inf {name}={int((~np.isfinite(X)).sum())}")
         print(f"[WORKER][{tag}] " + " / ".join(parts), file=self.log)
 
@@ -177,7 +202,8 @@ class DagCholeskyWorker(ArmoniKWorker):
                 if st:
                     return st
                 if self.verbose:
-                    print(f"[WORKER][POTRF] diag min={A[::B + 1].min()}", file=self.log)
+                    Ah = A.host() if isinstance(A, _DevTile) else A
+                    print(f"[WORKER][POTRF] diag min={Ah[::B + 1].min()}", file=self.log)
                 t0 = time.perf_counter()
                 info = self.backend.potrf(A, B)
                 secs = time.perf_counter() - t0
