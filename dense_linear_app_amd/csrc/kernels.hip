@@ -241,6 +241,13 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
+      // The group's own fragments were requested a whole group (1024 cycles) ago, so the
+      // wait in front of its first MFMA is free; the NEXT group's fragment reads are issued
+      // only after that first MFMA -- issued before it, the compiler's lgkmcnt(0) would also
+      // wait for them and expose a full LDS round trip in front of every group.
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = Tr<T>::mfma(fb[ks & 1][0][0], fa[ks & 1][0][0], acc[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
       if (ks + 1 < BK / 4)
         fread((ks + 1) & 1, cur, ks + 1);
       else if (!DMA && kt + 1 < nk)
@@ -250,7 +257,8 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          acc[a][b] = Tr<T>::mfma(fb[ks & 1][b / EPV][b % EPV], fa[ks & 1][a / EPV][a % EPV], acc[a][b]);
+          if (a + b > 0)
+            acc[a][b] = Tr<T>::mfma(fb[ks & 1][b / EPV][b % EPV], fa[ks & 1][a / EPV][a % EPV], acc[a][b]);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
