@@ -20,6 +20,8 @@ using namespace cholmi;
 
 struct chol_desc {
   int dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q;
+  int mbi, bsizi;    // stored tile edge / size: mb rounded up to 128 when the library owns a padded image
+  bool padded;       // stored tiles are larger than (mb, nb) and/or the last tile row/column is ragged
   int mt, nt;        // global tile grid
   int prow, pcol;    // this process's grid coordinates
   int lmt, lnt;      // local tile grid
@@ -110,14 +112,14 @@ LocalMat local_mat(const chol_desc *d, void *base) {
   L.lmt = d->lmt;
   L.P = d->p;
   L.Q = d->q;
-  L.mb = d->mb;
-  L.bsiz = d->bsiz;
+  L.mb = d->mbi;
+  L.bsiz = d->bsizi;
   return L;
 }
 
 template <typename T>
 T *local_tile(const chol_desc *d, void *base, int I, int J) {
-  return reinterpret_cast<T *>(base) + ((long)(I / d->p) + (long)(J / d->q) * d->lmt) * (long)d->bsiz;
+  return reinterpret_cast<T *>(base) + ((long)(I / d->p) + (long)(J / d->q) * d->lmt) * (long)d->bsizi;
 }
 
 bool single_tile_square(const chol_desc *d) {
@@ -171,8 +173,8 @@ int read_info(int *info) {
 // ---- whole-matrix right-looking tiled Cholesky on one GPU --------------------
 template <typename T>
 int potrf_full_device(chol_desc *d, void *base) {
-  const int nt = d->nt, mb = d->mb;
-  const long bsiz = d->bsiz;
+  const int nt = d->nt, mb = d->mbi;
+  const long bsiz = d->bsizi;
   T *M = reinterpret_cast<T *>(base);
   T *winv = reinterpret_cast<T *>(g.winv);
   int rc = ensure_events(2 * (size_t)nt + 4 + (g.profiling ? 4 * (size_t)nt : 0));
@@ -244,6 +246,8 @@ int potrf_full_device(chol_desc *d, void *base) {
   int info = 0;
   rc = read_info(&info);
   if (rc) return rc;
+  if (info > 0 && d->mbi != d->mb)  // stored index -> index in the caller's matrix
+    info = ((info - 1) / d->mbi) * d->mb + (info - 1) % d->mbi + 1;
   return info;
 }
 
@@ -286,10 +290,11 @@ static int potrf_impl(chol_desc *A) {
     return fail(CHOL_ERR_NOT_SUPPORTED,
                 "potrf_tile on a distributed descriptor: use the chol_wave_* building blocks");
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
-  if ((size_t)(A->mb / MACRO) * MACRO * MACRO * sizeof(T) > g.winv_bytes)
+  if ((size_t)(A->mbi / MACRO) * MACRO * MACRO * sizeof(T) > g.winv_bytes)
     return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: tile size above 4096");
   if (A->on_device) return potrf_full_device<T>(A, A->mat);
   // host-resident tiled matrix: stage the whole matrix through HBM
+  if (A->padded) return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: padded image over a host buffer");
   const size_t bytes = (size_t)A->mt * A->nt * A->bsiz * sizeof(T);
   void *dev = nullptr;
   if (hipMalloc(&dev, bytes) != hipSuccess) {
@@ -457,16 +462,28 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
   if (d->lmt < 0) d->lmt = 0;
   if (d->lnt < 0) d->lnt = 0;
   const bool multi = d->mt > 1 || d->nt > 1;
-  if (multi && (lm % mb || ln % nb))
-    return delete d, fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: ragged edge tiles are not supported");
-  if (multi && (mb != nb || mb % MACRO))
-    return delete d, fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: tiled matrices need mb == nb, a multiple of 128");
+  d->mbi = mb;
+  d->bsizi = bsiz;
+  d->padded = false;
+  if (multi && (lm % mb || ln % nb || mb % MACRO)) {
+    // ragged order and/or a tile edge that is not a multiple of 128 (the reference's sweep
+    // uses NB = 192 ... 448): the library keeps its own image with tiles rounded up to 128
+    // and the identity outside the matrix.  Needs library-owned storage on one process.
+    if (mat || p * q != 1 || mb != nb || lm != ln)
+      return delete d, fail(CHOL_ERR_NOT_SUPPORTED,
+                            "desc_create: ragged / non-128 tiles need mat == NULL, p*q == 1, a square matrix");
+    d->mbi = roundup(mb, MACRO);
+    d->bsizi = d->mbi * d->mbi;
+    d->padded = true;
+  }
+  if (multi && mb != nb)
+    return delete d, fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: tiled matrices need mb == nb");
   if (mat) {
     d->mat = mat;
     d->owns = false;
     d->on_device = is_device_ptr(mat);
   } else {
-    const size_t bytes = (size_t)std::max(1, d->lmt) * std::max(1, d->lnt) * (size_t)bsiz * d->esize;
+    const size_t bytes = (size_t)std::max(1, d->lmt) * std::max(1, d->lnt) * (size_t)d->bsizi * d->esize;
     hipError_t e = hipMalloc(&d->mat, bytes);
     if (e != hipSuccess) {
       delete d;
@@ -475,6 +492,14 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     }
     d->owns = true;
     d->on_device = true;
+    if (d->padded) {  // zero everywhere, identity on the diagonal tiles' diagonals
+      const LocalMat Lm = local_mat(d, d->mat);
+      if (dtype == CHOL_REAL_DOUBLE)
+        launch_plgsy<double>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0);
+      else
+        launch_plgsy<float>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0);
+      (void)hipStreamSynchronize(g.s_main);
+    }
   }
   if (multi) {
     int rc = build_worklist(d);
@@ -500,7 +525,7 @@ int chol_desc_destroy(chol_desc_t **desc) {
 
 void *chol_desc_local_ptr(chol_desc_t *d, size_t *bytes) {
   if (!d) return nullptr;
-  if (bytes) *bytes = (size_t)d->lmt * d->lnt * (size_t)d->bsiz * d->esize;
+  if (bytes) *bytes = (size_t)d->lmt * d->lnt * (size_t)d->bsizi * d->esize;
   return d->mat;
 }
 
@@ -584,20 +609,26 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
   std::lock_guard<std::mutex> lk(g_mu);
   const LocalMat L = local_mat(A, A->mat);
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed);
+    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm);
   else
-    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed);
+    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm);
   HIPCHECK(hipStreamSynchronize(g.s_main));
   return 0;
 }
+
+// valid extent of tile (I,J) inside the matrix (edge tiles are smaller)
+static inline int tile_rows(const chol_desc *d, int I) { return std::min(d->mb, d->lm - I * d->mb); }
+static inline int tile_cols(const chol_desc *d, int J) { return std::min(d->nb, d->ln - J * d->nb); }
 
 int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
   if (!d || !host_tile) return fail(-1, "tile_upload: NULL");
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_upload: tile not owned by this process");
   char *dst = reinterpret_cast<char *>(d->mat) +
-              ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsiz * d->esize;
-  HIPCHECK(hipMemcpy(dst, host_tile, (size_t)d->bsiz * d->esize, hipMemcpyDefault));
+              ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsizi * d->esize;
+  // host tile: mb x nb, ld = mb (Chameleon tile); only the part inside the matrix is stored
+  HIPCHECK(hipMemcpy2D(dst, (size_t)d->mbi * d->esize, host_tile, (size_t)d->mb * d->esize,
+                       (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
   return 0;
 }
 
@@ -606,8 +637,10 @@ int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_download: tile not owned by this process");
   const char *src = reinterpret_cast<const char *>(d->mat) +
-                    ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsiz * d->esize;
-  HIPCHECK(hipMemcpy(host_tile, src, (size_t)d->bsiz * d->esize, hipMemcpyDefault));
+                    ((size_t)(I / d->p) + (size_t)(J / d->q) * d->lmt) * (size_t)d->bsizi * d->esize;
+  if (tile_rows(d, I) < d->mb || tile_cols(d, J) < d->nb) memset(host_tile, 0, (size_t)d->bsiz * d->esize);
+  HIPCHECK(hipMemcpy2D(host_tile, (size_t)d->mb * d->esize, src, (size_t)d->mbi * d->esize,
+                       (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
   return 0;
 }
 
@@ -617,10 +650,10 @@ int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
   if (lda < d->lm) return fail(-2, "lapack_to_tile: lda");
   for (int J = 0; J < d->nt; ++J)
     for (int I = 0; I < d->mt; ++I) {
-      char *dst = reinterpret_cast<char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsiz * d->esize;
+      char *dst = reinterpret_cast<char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsizi * d->esize;
       const char *src = reinterpret_cast<const char *>(A) + ((size_t)I * d->mb + (size_t)J * d->nb * lda) * d->esize;
-      HIPCHECK(hipMemcpy2D(dst, (size_t)d->mb * d->esize, src, (size_t)lda * d->esize,
-                           (size_t)d->mb * d->esize, d->nb, hipMemcpyDefault));
+      HIPCHECK(hipMemcpy2D(dst, (size_t)d->mbi * d->esize, src, (size_t)lda * d->esize,
+                           (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
     }
   return 0;
 }
@@ -631,10 +664,10 @@ int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
   if (lda < d->lm) return fail(-3, "tile_to_lapack: lda");
   for (int J = 0; J < d->nt; ++J)
     for (int I = 0; I < d->mt; ++I) {
-      const char *src = reinterpret_cast<const char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsiz * d->esize;
+      const char *src = reinterpret_cast<const char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * (size_t)d->bsizi * d->esize;
       char *dst = reinterpret_cast<char *>(A) + ((size_t)I * d->mb + (size_t)J * d->nb * lda) * d->esize;
-      HIPCHECK(hipMemcpy2D(dst, (size_t)lda * d->esize, src, (size_t)d->mb * d->esize,
-                           (size_t)d->mb * d->esize, d->nb, hipMemcpyDefault));
+      HIPCHECK(hipMemcpy2D(dst, (size_t)lda * d->esize, src, (size_t)d->mbi * d->esize,
+                           (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
     }
   return 0;
 }
@@ -642,14 +675,16 @@ int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
 int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "residual before chol_init");
   if (!L || !rel) return fail(-1, "residual: NULL");
-  if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mb % MACRO)
+  if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mbi % MACRO)
     return fail(CHOL_ERR_NOT_SUPPORTED, "residual: single-process device-resident square tiled matrix only");
   std::lock_guard<std::mutex> lk(g_mu);
   HIPCHECK(hipMemsetAsync(g.d_acc, 0, 2 * sizeof(double), g.s_main));
   if (L->dtype == CHOL_REAL_DOUBLE)
-    launch_residual<double>(g.s_main, reinterpret_cast<const double *>(L->mat), L->nt, L->mb, bump, seed, g.d_acc);
+    launch_residual<double>(g.s_main, reinterpret_cast<const double *>(L->mat), L->nt, L->mbi, bump, seed,
+                            g.d_acc, L->mb, (long)L->lm);
   else
-    launch_residual<float>(g.s_main, reinterpret_cast<const float *>(L->mat), L->nt, L->mb, bump, seed, g.d_acc);
+    launch_residual<float>(g.s_main, reinterpret_cast<const float *>(L->mat), L->nt, L->mbi, bump, seed,
+                           g.d_acc, L->mb, (long)L->lm);
   double h[2];
   HIPCHECK(hipMemcpyAsync(h, g.d_acc, sizeof h, hipMemcpyDeviceToHost, g.s_main));
   HIPCHECK(hipStreamSynchronize(g.s_main));
@@ -681,7 +716,7 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   PanelRef pan;
   memset(&pan, 0, sizeof pan);
   pan.P = 1;
-  pan.base[0] = (char *)d->mat + (size_t)k * d->nt * d->bsiz * d->esize;
+  pan.base[0] = (char *)d->mat + (size_t)k * d->nt * d->bsizi * d->esize;
   const LocalMat C = local_mat(d, d->mat);
   const int ntiles = d->ge[k + 1];
   cholmi::g_ablate = ablate;
@@ -701,7 +736,7 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   cholmi::g_ablate = 0;
   *ms = best;
   const double ntl = (double)(d->nt - 1 - k);
-  if (flops) *flops = (ntl * (ntl - 1) + ntl) * (double)d->mb * d->mb * d->mb;
+  if (flops) *flops = (ntl * (ntl - 1) + ntl) * (double)d->mbi * d->mbi * d->mbi;
   return 0;
 }
 
@@ -774,9 +809,9 @@ int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
   if (!d || !lkk) return fail(-1, "wave_potrf: NULL");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_potrf_tile<double>(s, (double *)lkk, d->mb, (double *)g.winv, g.d_info, k * d->mb);
+    launch_potrf_tile<double>(s, (double *)lkk, d->mbi, (double *)g.winv, g.d_info, k * d->mbi);
   else
-    launch_potrf_tile<float>(s, (float *)lkk, d->mb, (float *)g.winv, g.d_info, k * d->mb);
+    launch_potrf_tile<float>(s, (float *)lkk, d->mbi, (float *)g.winv, g.d_info, k * d->mbi);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -786,9 +821,9 @@ int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
   if (!d || !lkk) return fail(-1, "wave_invert_diag: NULL");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_invert_diag<double>(s, (const double *)lkk, d->mb, (double *)g.winv);
+    launch_invert_diag<double>(s, (const double *)lkk, d->mbi, (double *)g.winv);
   else
-    launch_invert_diag<float>(s, (const float *)lkk, d->mb, (float *)g.winv);
+    launch_invert_diag<float>(s, (const float *)lkk, d->mbi, (float *)g.winv);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -801,13 +836,13 @@ int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   const int il0 = (k + d->p - d->prow) / d->p;  // first local row with global index > k
   const int cnt = d->lmt - il0;
   if (cnt <= 0) return 0;
-  const size_t off = ((size_t)il0 + (size_t)(k / d->q) * d->lmt) * (size_t)d->bsiz;
+  const size_t off = ((size_t)il0 + (size_t)(k / d->q) * d->lmt) * (size_t)d->bsizi;
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_trsm_panel<double>(s, (double *)d->mat + off, d->bsiz, cnt, (const double *)lkk,
-                              (const double *)g.winv, d->mb, 1.0);
+    launch_trsm_panel<double>(s, (double *)d->mat + off, d->bsizi, cnt, (const double *)lkk,
+                              (const double *)g.winv, d->mbi, 1.0);
   else
-    launch_trsm_panel<float>(s, (float *)d->mat + off, d->bsiz, cnt, (const float *)lkk,
-                             (const float *)g.winv, d->mb, 1.0f);
+    launch_trsm_panel<float>(s, (float *)d->mat + off, d->bsizi, cnt, (const float *)lkk,
+                             (const float *)g.winv, d->mbi, 1.0f);
   HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -62,13 +62,13 @@ void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T 
 
 template <typename T>
 void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
-                  unsigned long long seed);
+                  unsigned long long seed, int mbu, long nglob);
 
 // accumulates sum((LL^T - A)^2) and sum(A^2) over the lower triangle (strict part
 // counted twice) into acc[0], acc[1] (device doubles).  Single process only.
 template <typename T>
 void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
-                     unsigned long long seed, double *d_acc);
+                     unsigned long long seed, double *d_acc, int mbu, long nglob);
 
 // pad helpers for the staged 1-tile path: dst is ldp x ldp (zeroed), identity on
 // the padded part of the diagonal when `unit_pad`.

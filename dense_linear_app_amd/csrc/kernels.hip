@@ -824,17 +824,27 @@ __device__ __forceinline__ double plgsy_entry(double bump, uint64_t seed, long i
   return (i == j) ? v + bump : v;
 }
 
+// mbu = the caller's tile edge, nglob = matrix order.  The stored tile edge A.mb may be
+// larger (rounded up to 128) and the last tile row/column may be ragged: positions outside
+// the matrix hold the identity (1 on the diagonal of diagonal tiles, 0 elsewhere), which
+// leaves the factor of the real part untouched.
 template <typename T>
 __global__ __launch_bounds__(256) void k_plgsy(LocalMat A, int lnt, int prow, int pcol, double bump,
-                                               unsigned long long seed) {
+                                               unsigned long long seed, int mbu, long nglob) {
   const long per_tile = A.bsiz;
   const long total = (long)A.lmt * lnt * per_tile;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long tl = idx / per_tile, e = idx - tl * per_tile;
     const int il = (int)(tl % A.lmt), jl = (int)(tl / A.lmt);
-    const long gi = ((long)il * A.P + prow) * A.mb + e % A.mb;
-    const long gj = ((long)jl * A.Q + pcol) * A.mb + e / A.mb;
-    reinterpret_cast<T *>(A.base)[idx] = (T)plgsy_entry(bump, seed, gi, gj);
+    const int ii = (int)(e % A.mb), jj = (int)(e / A.mb);
+    const long I = (long)il * A.P + prow, J = (long)jl * A.Q + pcol;
+    const long gi = I * mbu + ii, gj = J * mbu + jj;
+    T v;
+    if (ii < mbu && jj < mbu && gi < nglob && gj < nglob)
+      v = (T)plgsy_entry(bump, seed, gi, gj);
+    else
+      v = (I == J && ii == jj) ? T(1) : T(0);
+    reinterpret_cast<T *>(A.base)[idx] = v;
   }
 }
 
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(256) void k_plgsy(LocalMat A, int lnt, int prow, in
 template <typename T>
 __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int Nb, int mb, int nbm,
                                                      double bump, unsigned long long seed,
-                                                     double *acc_out) {
+                                                     double *acc_out, int mbu, long nglob) {
   __shared__ Smem<T> sm;
   __shared__ double red[2][4];
   const int MT = nbm * nbm;
@@ -878,8 +888,10 @@ __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int N
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long gi = (long)i * mb + mi * MACRO + wr * 64 + a * 16 + (lane & 15);
-        const long gj = (long)j * mb + mj * MACRO + wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+        const int ii = mi * MACRO + wr * 64 + a * 16 + (lane & 15);
+        const int jj = mj * MACRO + wc * 64 + b * 16 + Tr<T>::drow(lane, r);
+        const long gi = (long)i * mbu + ii, gj = (long)j * mbu + jj;
+        if (ii >= mbu || jj >= mbu || gi >= nglob || gj >= nglob) continue;  // padding
         if (gi < gj) continue;
         const double aij = (double)(T)plgsy_entry(bump, seed, gi, gj);
         const double d = (double)acc[a][b][r] - aij;
@@ -981,16 +993,16 @@ void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T 
 
 template <typename T>
 void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
-                  unsigned long long seed) {
-  k_plgsy<T><<<4096, 256, 0, s>>>(A, lnt, prow, pcol, bump, seed);
+                  unsigned long long seed, int mbu, long nglob) {
+  k_plgsy<T><<<4096, 256, 0, s>>>(A, lnt, prow, pcol, bump, seed, mbu, nglob);
 }
 
 template <typename T>
 void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
-                     unsigned long long seed, double *d_acc) {
+                     unsigned long long seed, double *d_acc, int mbu, long nglob) {
   const int nbm = mb / MACRO;
   const long ntile = (long)Nb * (Nb + 1) / 2;
-  k_residual<T><<<dim3((unsigned)(ntile * nbm * nbm)), 256, 0, s>>>(Lbase, Nb, mb, nbm, bump, seed, d_acc);
+  k_residual<T><<<dim3((unsigned)(ntile * nbm * nbm)), 256, 0, s>>>(Lbase, Nb, mb, nbm, bump, seed, d_acc, mbu, nglob);
 }
 
 template <typename T>
@@ -1042,9 +1054,9 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
   template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
   template void launch_gemm_nt_tile<T>(hipStream_t, const T *, const T *, T *, int, T, T, bool);    \
   template void launch_plgsy<T>(hipStream_t, const LocalMat &, int, int, int, double,               \
-                                unsigned long long);                                                \
+                                unsigned long long, int, long);                                     \
   template void launch_residual<T>(hipStream_t, const T *, int, int, double, unsigned long long,    \
-                                   double *);                                                       \
+                                   double *, int, long);                                            \
   template void launch_pad_identity<T>(hipStream_t, T *, int, int);
 INSTANTIATE(double)
 INSTANTIATE(float)

@@ -104,8 +104,6 @@ def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None,
             w.writerow(CSV_HEADER)
     for N in Ns:
         for NB in NBs:
-            if N % NB:
-                continue
             d = ch.CHAMELEON_Desc_Create(None, dtype, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1)
             for r in range(repeats):
                 ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, seed)

@@ -68,13 +68,44 @@ def test_ops_reject_null_and_mismatched_descriptors(cham):
 
 def test_whole_matrix_descriptor_restrictions(cham):
     ch = cham
+    # ragged order / non-128 tiles are served from a library-owned padded image only
+    buf = np.zeros(1024 * 1024)
     with pytest.raises(ch.CholmiError, match="ragged"):
-        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 256, 256, 256 * 256, 1000, 1000, 0, 0, 1000, 1000, 1, 1)
-    with pytest.raises(ch.CholmiError, match="multiple of 128"):
-        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 200, 200, 200 * 200, 800, 800, 0, 0, 800, 800, 1, 1)
+        ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, 256, 256, 256 * 256, 1000, 1000, 0, 0, 1000, 1000, 1, 1)
+    with pytest.raises(ch.CholmiError, match="mb == nb"):
+        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 256, 128, 256 * 128, 1024, 1024, 0, 0, 1024, 1024, 1, 1)
     d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, 256, 256, 256 * 256, 512, 1024, 0, 0, 512, 1024, 1, 1)
     with pytest.raises(ch.CholmiError, match="not square"):
         ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+
+
+@pytest.mark.parametrize("N,NB", [(1000, 192), (1000, 128), (5000, 448), (2000, 320), (777, 256)])
+def test_reference_sweep_shapes_ragged_and_odd_tiles(cham, N, NB):
+    """The VM sweep's grid (benchmark.c:76-80: N in {1000, 5000, ...}, NB = 128..512 step 64):
+    order not a multiple of the tile, tile not a multiple of 128.  Edge tiles are smaller, not
+    zero-padded (v6_test.c:44 descriptor semantics); the library keeps a padded image inside."""
+    ch = cham
+    d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    A = d.to_lapack()
+    assert A.shape == (N, N) and np.array_equal(A, A.T) and np.diag(A).min() > N - 1
+    from oracle import oracle as orc
+
+    assert A[N - 1, 3] == orc.plgsy_entry(float(N), 42, N - 1, 3)  # same generator, global indices
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(d.to_lapack())
+    Lref = np.linalg.cholesky(A)
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-12
+    assert ch.residual_plgsy(d, float(N), 42) <= 1e-13
+    # a user matrix through Lapack_to_Tile, and the pivot index of a non-SPD one in GLOBAL numbering
+    M = A.copy(order="F")
+    bad = N - 7
+    M[bad, bad] = -1.0
+    d.from_lapack(M)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == bad + 1
+    t = d.download_tile(d.mt - 1, 0)
+    rows = N - (d.mt - 1) * NB
+    assert t.shape == (NB, NB) and not t[rows:, :].any()
 
 
 def test_host_resident_tiled_matrix_is_staged(cham, orc):
