@@ -110,6 +110,14 @@ class HipEngine:
     def wait(self, waiter, waited) -> None:
         waiter.wait_stream(waited)
 
+    def record(self, stream):
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def wait_event(self, stream, ev) -> None:
+        stream.wait_event(ev)
+
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.dev)
 
@@ -154,11 +162,20 @@ class BlockCyclicCholesky:
     of the panel instead of a ring carrying all of it.  Same result, same panel addressing.
     """
 
-    def __init__(self, engine, dist, lookahead: bool = True, panel_mode: Optional[str] = None):
+    def __init__(self, engine, dist, lookahead: bool = True, panel_mode: Optional[str] = None,
+                 panel_first: Optional[bool] = None):
         import os
 
         self.e, self.dist, self.lookahead = engine, dist, lookahead
         self.panel_mode = panel_mode or os.environ.get("CHOLMI_PANEL_MODE", "bcast")
+        # On the ranks that factor / solve panel k+1, hold back the bulk of update k until their
+        # panel kernels are done.  Beside a running trailing update those latency-bound kernels run
+        # 3-5x slower (DESIGN.md section 3) and they are on every rank's critical path, while the
+        # held-back update costs one rank ~1 ms per wave.  Only worth it with several GPUs.
+        env = os.environ.get("CHOLMI_PANEL_FIRST")
+        self.panel_first = (dist.get_world_size() > 1) if panel_first is None and env is None else (
+            panel_first if panel_first is not None else env == "1")
+        self._panel_done = None
         assert self.panel_mode in ("bcast", "allgather")
         e = engine
         self.world = dist.get_world_size()
@@ -224,6 +241,8 @@ class BlockCyclicCholesky:
                 e.invert_diag(lkk, s)
         if k + 1 < e.nt:
             e.trsm(k, lkk, s)
+        if self.panel_first:
+            self._panel_done = e.record(s)  # this rank's share of the panel computation is enqueued
 
     def _part(self, k: int, p2: int):
         """(first local row, tile count) of the part of panel k owned by process row p2."""
@@ -314,8 +333,11 @@ class BlockCyclicCholesky:
                 # column k+1 first, so that panel k+1 can start under the rest of update k
                 e.update(k, k + 1, k + 2, bases, firsts, main)
                 e.wait(side, main)
+                self._panel_done = None
                 with e.stream_ctx(side):
                     panel = self._panel(k + 1, side)
+                if self._panel_done is not None:
+                    e.wait_event(main, self._panel_done)
                 e.update(k, k + 2, e.nt, bases, firsts, main)
             else:
                 e.update(k, k + 1, e.nt, bases, firsts, main)

@@ -60,6 +60,12 @@ class OracleEngine:
     def wait(self, a, b):
         pass
 
+    def record(self, s):
+        return object()
+
+    def wait_event(self, s, ev):
+        pass
+
     def synchronize(self):
         pass
 
