@@ -130,3 +130,19 @@ def test_full_potrf_large_properties(cham, N, B):
     for k in (0, N // B - 1):
         t = d.download_tile(k, k)
         assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
+
+
+@pytest.mark.parametrize("N,B,dtype,tol", [(65536, 1024, "f64", 1e-13), (65536, 1024, "f32", 5e-5)])
+def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
+    """BASELINE configs 4/5 at their per-matrix size on one GPU: factor, residual of the
+    regenerated matrix, positive finite diagonal, untouched strictly-upper tile."""
+    ch = cham
+    dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
+    d = full_desc(ch, N, B, dt)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    upper_before = d.download_tile(3, 40)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    assert ch.residual_plgsy(d, float(N), 42) <= tol
+    assert np.array_equal(d.download_tile(3, 40), upper_before)
+    t = d.download_tile(N // B - 1, N // B - 1)
+    assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
