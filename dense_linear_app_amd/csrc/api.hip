@@ -539,14 +539,32 @@ int chol_desc_local_tiles(chol_desc_t *d, int *lmt, int *lnt) {
 // ---------------------------------------------------------------- POTRF
 int chol_potrf_tile(int uplo, chol_desc_t *A) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_tile before chol_init");
-  if (uplo != CHOL_LOWER)
-    return fail(uplo == CHOL_UPPER ? CHOL_ERR_NOT_SUPPORTED : -1, "potrf_tile: only ChamLower");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrf_tile: uplo");
   if (!A) return fail(-2, "potrf_tile: NULL descriptor");
   std::lock_guard<std::mutex> lk(g_mu);
-  return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
+  if (uplo == CHOL_LOWER)
+    return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
+  // ChamUpper: A = U^T U with U = L^T.  Transpose the stored matrix in place (its upper
+  // triangle becomes the lower one), factor Lower, transpose back: the upper triangle now
+  // holds U and the caller's strict lower triangle is bit-for-bit what it was.
+  const bool one = single_tile_square(A);
+  if (!one && (A->p * A->q != 1 || !A->on_device || A->mt != A->nt))
+    return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile(Upper): single-process device-resident square matrices");
+  if (one && !(A->on_device && A->mb % MACRO == 0))
+    return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile(Upper) on a staged 1-tile descriptor");
+  auto flip = [&]() {
+    if (A->dtype == CHOL_REAL_DOUBLE)
+      launch_transpose_inplace<double>(g.s_main, (double *)A->mat, A->nt, A->mbi);
+    else
+      launch_transpose_inplace<float>(g.s_main, (float *)A->mat, A->nt, A->mbi);
+  };
+  flip();
+  const int rc = A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
+  flip();
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return rc;
 }
 
-// ---------------------------------------------------------------- TRSM
 int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_desc_t *A,
                    chol_desc_t *B) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "trsm_tile before chol_init");

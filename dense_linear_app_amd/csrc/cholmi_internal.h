@@ -75,6 +75,10 @@ void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
 template <typename T>
 void launch_pad_identity(hipStream_t s, T *dst, int n, int ldp);
 
+// in-place transpose of a whole nt x nt tile matrix (mb multiple of 64)
+template <typename T>
+void launch_transpose_inplace(hipStream_t s, T *M, int nt, int mb);
+
 // register-only MFMA stream (blocks x 256 threads, 16 MFMA per wave per iteration)
 template <typename T>
 void launch_mfma_probe(hipStream_t s, T *out, int blocks, int iters);

@@ -121,7 +121,7 @@ __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk && !(ablate & 1)) gload((kt + 1) * BK);
+    if (kt + 1 < nk && !(ablate & 1)) gload((ablate & 32) ? 0 : (kt + 1) * BK);  // 32: cache-hot loads
     T af[4], bf[4];
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -913,6 +913,48 @@ __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int N
     atomicAdd(&acc_out[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
+
+// ------------------------------------------------------------------------------
+// In-place transpose of a whole tile-layout matrix (single process): tile (I,J) <-> tile
+// (J,I), both transposed, 64x64 sub-blocks through LDS.  Used to run ChamUpper through the
+// Lower kernels: A = U^T U with U = L^T, and since the Lower path never touches strictly-upper
+// storage, transposing back leaves the caller's strict lower triangle exactly as it was.
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose_inplace(T *M, int nt, int mb) {
+  __shared__ T sa[64][65], sb[64][65];
+  const int nsub = mb / 64;
+  // blockIdx.x enumerates tile pairs I >= J (row-major over the lower triangle) x sub-block pairs
+  const long per_pair = (long)nsub * nsub;
+  const long pair = blockIdx.x / per_pair, sub = blockIdx.x % per_pair;
+  int I = (int)((sqrt(8.0 * (double)pair + 1.0) - 1.0) * 0.5);
+  while ((long)I * (I + 1) / 2 > pair) --I;
+  while ((long)(I + 1) * (I + 2) / 2 <= pair) ++I;
+  const int J = (int)(pair - (long)I * (I + 1) / 2);
+  const int si = (int)(sub % nsub), sj = (int)(sub / nsub);
+  if (I == J && si < sj) return;  // the mirror sub-block of a diagonal tile is handled by (sj, si)
+  const long bsiz = (long)mb * mb;
+  T *ta = M + ((long)I + (long)J * nt) * bsiz + si * 64 + (long)sj * 64 * mb;  // sub-block (si,sj) of (I,J)
+  T *tb = M + ((long)J + (long)I * nt) * bsiz + sj * 64 + (long)si * 64 * mb;  // sub-block (sj,si) of (J,I)
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    sa[c][tx] = ta[tx + (long)c * mb];
+    sb[c][tx] = tb[tx + (long)c * mb];
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    ta[tx + (long)c * mb] = sb[tx][c];
+    tb[tx + (long)c * mb] = sa[tx][c];
+  }
+}
+
+template <typename T>
+void launch_transpose_inplace(hipStream_t s, T *M, int nt, int mb) {
+  const long pairs = (long)nt * (nt + 1) / 2, nsub = mb / 64;
+  k_transpose_inplace<T><<<dim3((unsigned)(pairs * nsub * nsub)), 256, 0, s>>>(M, nt, mb);
+}
+template void launch_transpose_inplace<double>(hipStream_t, double *, int, int);
+template void launch_transpose_inplace<float>(hipStream_t, float *, int, int);
 
 template <typename T>
 __global__ void k_pad_identity(T *dst, int n, int ldp) {

@@ -89,8 +89,10 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
 int chol_desc_destroy(chol_desc_t **desc);
 
 /* CHAMELEON_dpotrf_Tile(uplo, A) W2:238, V6:56 (spotrf by descriptor dtype).
- * Lower only.  Works on a 1-tile descriptor (worker path) and on a whole tiled
- * matrix (driver path: the full wave DAG of C2:506-565 runs on the device). */
+ * Works on a 1-tile descriptor (worker path) and on a whole tiled matrix (driver path: the
+ * full wave DAG of C2:506-565 runs on the device).  ChamUpper is served for device-resident
+ * matrices by transposing the storage in place around the Lower factorisation (the strict
+ * lower triangle is returned untouched). */
 int chol_potrf_tile(int uplo, chol_desc_t *A);
 
 /* CHAMELEON_dtrsm_Tile(side, uplo, trans, diag, alpha, A, B) W2:323.

@@ -12,7 +12,7 @@ for N, B in cfgs:
     D = 0x100  # diagnostic kernel (register staging) with ablation bits
     variants = [(0, "production (paired, LDS-DMA)"), (D, "diag baseline"), (0, "production again")]
     if os.environ.get("ABLATE") == "1":
-        variants += [(D | 4, "diag: no C read"), (D | 1, "diag: no global loads"), (D | 2, "diag: no LDS reads"),
+        variants += [(D | 32, "diag: cache-hot global loads"), (D | 4, "diag: no C read"), (D | 1, "diag: no global loads"), (D | 2, "diag: no LDS reads"),
                      (D | 8, "diag: no barrier"), (D | 3, "diag: no gl+lds"), (D | 15, "diag: mfma+store only")]
     for abl, name in variants:
         ms, tf = ch.bench_update(d, 0, abl, 3)

@@ -146,3 +146,25 @@ def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
     assert np.array_equal(d.download_tile(3, 40), upper_before)
     t = d.download_tile(N // B - 1, N // B - 1)
     assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
+
+
+@pytest.mark.parametrize("N,B", [(1024, 256), (2048, 512), (1000, 192)])
+def test_full_potrf_upper(cham, orc, N, B):
+    """ChamUpper (v3 driver's --uplo): A = U^T U in the upper triangle, the strict
+    lower triangle of the storage untouched."""
+    ch = cham
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamUpper, d, 42)
+    A = d.to_lapack()
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, d) == 0
+    R = d.to_lapack()
+    U = np.triu(R)
+    assert np.array_equal(np.tril(R, -1), np.tril(A, -1))
+    Lref = np.linalg.cholesky(A)
+    assert np.abs(U - Lref.T).max() / np.abs(Lref).max() <= 1e-12
+    assert np.linalg.norm(U.T @ U - A) / np.linalg.norm(A) <= 1e-13
+    # non-SPD: same info as Lower
+    M = A.copy(order="F")
+    M[N - 5, N - 5] = -2.0
+    d.from_lapack(M)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, d) == N - 4

@@ -145,7 +145,7 @@ def test_alpha_beta_and_flags(cham, orc):
     with pytest.raises(ch.CholmiError):
         ch.CHAMELEON_dtrsm_Tile(ch.ChamLeft, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, desc1(ch, Lm), desc1(ch, X))
     with pytest.raises(ch.CholmiError):
-        ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, desc1(ch, X))
+        ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, desc1(ch, X))  # Upper on a staged host tile: not covered
     with pytest.raises(ch.CholmiError):
         ch.CHAMELEON_dgemm_Tile(ch.ChamTrans, ch.ChamTrans, 1.0, desc1(ch, A), desc1(ch, Bm), 0.0, desc1(ch, Cn))
 
