@@ -45,6 +45,7 @@ struct Ctx {
   void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k)
   size_t winv_bytes = 0;
   int *d_info = nullptr;
+  int *d_ytab = nullptr;  // per-CU yield requests (kernels.hip: cooperative CU hand-over)
   double *d_acc = nullptr;
   void *stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_bytes[3] = {0, 0, 0};
@@ -180,6 +181,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   int rc = ensure_events(2 * (size_t)nt + 4 + (g.profiling ? 4 * (size_t)nt : 0));
   if (rc) return rc;
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
+  if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
   hipEvent_t ev_start = g.events[2 * nt], ev_stop = g.events[2 * nt + 1], ev_join = g.events[2 * nt + 2];
   HIPCHECK(hipEventRecord(ev_start, g.s_main));
   HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_start, 0));
@@ -210,12 +212,18 @@ int potrf_full_device(chol_desc *d, void *base) {
         p2 = g.events[2 * nt + 4 + 3 * k + 2];
         HIPCHECK(hipEventRecord(p0, g.s_main));
       }
-      launch_trail_update<T>(g.s_main, C, d->d_list, u1_lo, u1_hi - u1_lo, pan);
+      // Give CUs to the next panel's guest workgroups only when that panel is on the critical
+      // path, i.e. when this wave's update is not much longer than a panel (POTRF ~ (mb/128) x
+      // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
+      const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
+      const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
+      const bool yield = (double)u1_hi * t_tile < 6.0 * t_panel;
+      launch_trail_update<T>(g.s_main, C, d->d_list, u1_lo, u1_hi - u1_lo, pan, yield);
       if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
       HIPCHECK(hipEventRecord(ev_u1, g.s_main));
       HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
       if (u1_lo > 0) {
-        launch_trail_update<T>(g.s_main, C, d->d_list, 0, u1_lo, pan);
+        launch_trail_update<T>(g.s_main, C, d->d_list, 0, u1_lo, pan, yield);
         ++upd_launches;
       }
       if (g.profiling) HIPCHECK(hipEventRecord(p2, g.s_main));
@@ -399,6 +407,14 @@ int chol_init(int ncpu, int ngpu) {
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
   HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
   HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
+  {
+    const char *e = getenv("CHOLMI_YIELD");
+    if (!e || atoi(e) != 0) {
+      HIPCHECK(hipMalloc(&g.d_ytab, YTAB_ENTRIES * sizeof(int)));
+      HIPCHECK(hipMemset(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int)));
+      cholmi::g_ytab = g.d_ytab;
+    }
+  }
   g.inited = true;
   return 0;
 }
@@ -417,6 +433,9 @@ int chol_finalize(void) {
   (void)hipFree(g.winv);
   (void)hipFree(g.d_info);
   (void)hipFree(g.d_acc);
+  if (g.d_ytab) (void)hipFree(g.d_ytab);
+  g.d_ytab = nullptr;
+  cholmi::g_ytab = nullptr;
   (void)hipStreamDestroy(g.s_main);
   (void)hipStreamDestroy(g.s_panel);
   g.winv = nullptr;
@@ -883,9 +902,9 @@ int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const 
   const int lo = d->ge[jhi], hi = d->ge[jlo];
   const LocalMat C = local_mat(d, d->mat);
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_trail_update<double>(s, C, d->d_list, lo, hi - lo, pan);
+    launch_trail_update<double>(s, C, d->d_list, lo, hi - lo, pan, true);
   else
-    launch_trail_update<float>(s, C, d->d_list, lo, hi - lo, pan);
+    launch_trail_update<float>(s, C, d->d_list, lo, hi - lo, pan, true);
   HIPCHECK(hipGetLastError());
   return 0;
 }

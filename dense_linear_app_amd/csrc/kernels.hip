@@ -145,6 +145,42 @@ __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const
 }
 
 // ------------------------------------------------------------------------------
+// Cooperative CU hand-over.  The fp64 MFMA stream of a trailing-update wave occupies its
+// SIMD's issue for the whole 64 cycles of every MFMA, so a latency-bound kernel that lands
+// on the same CU (the single-workgroup diagonal-block factorisation, the handful of
+// workgroups of the in-tile POTRF steps) runs 4-6x slower than alone, whatever its wave
+// priority -- and it is on the critical path of every wave of the DAG.  Such a "guest"
+// workgroup therefore raises a counter in a per-CU table (indexed by the hardware XCC / SE /
+// SH / CU ids) for its lifetime; the update waves poll their CU's entry once per K-slice
+// (one relaxed agent-scope load, issued ahead of the slice's DMA and consumed at the slice's
+// barrier) and sleep while it is non-zero.  One CU of 256 pauses for the ~85 us a guest
+// needs; nothing else changes.  Bounded spin: a stale entry can only cost time.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int cu_slot() {
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // XCC_ID
+  return (int)(((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u) + ((hw >> 8) & 15u));
+}
+struct GuestOnCu {  // RAII-style bracket used by guest kernels (thread 0 only touches memory)
+  int *slot;
+  __device__ __forceinline__ explicit GuestOnCu(int *tab) : slot(nullptr) {
+    if (tab) {
+      slot = tab + cu_slot();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __device__ __forceinline__ void leave() {
+    if (slot && threadIdx.x == 0) __hip_atomic_fetch_add(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+__device__ __forceinline__ void yield_to_guest(const int *slot) {
+  for (int spin = 0; spin < 4000; ++spin) {  // <= ~2 ms
+    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+    __builtin_amdgcn_s_sleep(20);
+  }
+}
+
+// ------------------------------------------------------------------------------
 // "Paired" form of the NT core (trailing update): fragment rows are interleaved so that
 // lane i of a 16-lane group owns EPL = 16 B / sizeof(T) CONSECUTIVE rows (fp64: rows 2i,
 // 2i+1 of a 32-row group; fp32: rows 4i..4i+3 of the 64-row group).  One ds_read_b128
@@ -164,7 +200,7 @@ struct alignas(16) SmemP {
 template <typename T, bool DMA>
 __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda,
                                                 const T *__restrict__ B, int ldb, int K, Acc<T> &acc,
-                                                SmemP<T> &sm) {
+                                                SmemP<T> &sm, const int *yslot = nullptr) {
   using vec_t = typename Tr<T>::vec_t;
   constexpr int EPV = Tr<T>::EPV;  // elements per 16 bytes == EPL
   constexpr int NG = 4 / EPV;      // 16-lane row groups per 64 rows: fp64 2, fp32 1
@@ -232,6 +268,8 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+    int guest = 0;  // requested ahead of the DMA, looked at after the slice's MFMAs
+    if (yslot) guest = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fread(0, cur, 0);
     if (kt + 1 < nk) {
       if (DMA)
@@ -261,6 +299,7 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
             acc[a][b] = Tr<T>::mfma(fb[ks & 1][b / EPV][b % EPV], fa[ks & 1][a / EPV][a % EPV], acc[a][b]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (yslot && __builtin_amdgcn_readfirstlane(guest) != 0) yield_to_guest(yslot);
     __syncthreads();
   }
 }
@@ -420,7 +459,8 @@ __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const 
 
 template <typename T, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
-                                                           int ntiles, PanelRef pan, int nbm, int G) {
+                                                           int ntiles, PanelRef pan, int nbm, int G,
+                                                           const int *ytab) {
   __shared__ SmemP<T> sm;
   const int MT = nbm * nbm;
   const int b = blockIdx.x, x = b & 7, s = b >> 3;
@@ -437,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
           mi * MACRO + (long)mj * MACRO * C.mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm);
+  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, ytab ? ytab + cu_slot() : nullptr);
   if (diag && mi == mj)
     nt_epilogue_paired_impl<T, true>(Cp, C.mb, acc, T(-1), T(1));
   else
@@ -448,8 +488,10 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
 // contiguous tiles.  (TRSM by multiplication with the inverted 128x128 diagonal block.)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int mb, int nbm, int r0,
-                                                        int s, const T *__restrict__ winv, T alpha) {
+                                                        int s, const T *__restrict__ winv, T alpha,
+                                                        int *ytab) {
   __shared__ SmemP<T> sm;
+  GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nr = nbm - r0;
   const int tix = blockIdx.x / nr, r = r0 + blockIdx.x % nr;
@@ -459,13 +501,15 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
   acc_zero<T>(acc);
   nt_kloop_paired<T, true>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
   nt_epilogue_paired<T>(Ap, mb, acc, alpha, T(0), false);
+  guest.leave();
 }
 
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, int mb, int nbm, int s,
-                                                         const T *__restrict__ lkk, T beta) {
+                                                         const T *__restrict__ lkk, T beta, int *ytab) {
   __shared__ SmemP<T> sm;
+  GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nc = nbm - 1 - s;
   int b = blockIdx.x;
@@ -480,15 +524,17 @@ __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, in
   acc_zero<T>(acc);
   nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
   nt_epilogue_paired<T>(Cp, mb, acc, T(-1), beta, false);
+  guest.leave();
 }
 
 // in-tile trailing update of the blocked POTRF: C[r,c] -= X[r,s] X[c,s]^T, r >= c > s
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s) {
+__global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s, int *ytab) {
   __shared__ SmemP<T> sm;
   __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int r = s + 1 + blockIdx.x, c = s + 1 + blockIdx.y;
   if (c > r) return;
+  GuestOnCu guest(ytab);
   const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
   const T *Bp = tile + c * MACRO + (long)s * MACRO * mb;
   T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
@@ -496,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int n
   acc_zero<T>(acc);
   nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
   nt_epilogue_paired<T>(Cp, mb, acc, T(-1), T(1), r == c);
+  guest.leave();
 }
 
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
@@ -788,9 +835,10 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 template <typename T>
 __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
                                                     int info_base, int factor,
-                                                    unsigned long long *dbg) {
+                                                    unsigned long long *dbg, int *ytab) {
   __shared__ DiagLds<T> L;
   __shared__ unsigned long long slot_s;
+  GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(3);
   unsigned long long t0 = 0;
   unsigned long long *ph = nullptr;
@@ -805,6 +853,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict_
     ph[-2] = t0;
     ph[-1] = __builtin_amdgcn_s_memrealtime();
   }
+  guest.leave();
 }
 
 // ------------------------------------------------------------------------------
@@ -965,13 +1014,14 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------
+int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU hand-over), may be null
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int ntiles,
-                         const PanelRef &pan) {
+                         const PanelRef &pan, bool yield) {
   if (ntiles <= 0) return;
   const int nbm = C.mb / MACRO, MT = nbm * nbm;
   int G = 64 / MT;
@@ -982,9 +1032,9 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
     k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G, g_ablate & 255);
   else if (g_variant == 1)
-    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
+    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G, yield ? g_ytab : nullptr);
   else
-    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G);
+    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, ntiles, pan, nbm, G, yield ? g_ytab : nullptr);
 }
 
 template <typename T>
@@ -992,11 +1042,12 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
   const int nbm = mb / MACRO;
   for (int st = 0; st < nbm; ++st) {
     k_potrf_diag<T><<<1, 256, 0, s>>>(tile + (long)st * MACRO * (mb + 1), mb,
-                                      winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1, g_dbg);
+                                      winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1, g_dbg, g_ytab);
     const int nr = nbm - 1 - st;
     if (nr > 0) {
-      k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1));
-      k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st);
+      // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
+      k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1), g_ytab);
+      k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st, g_ytab);
     }
   }
 }
@@ -1006,7 +1057,7 @@ void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
   const int nbm = mb / MACRO;
   for (int st = 0; st < nbm; ++st)
     k_potrf_diag<T><<<1, 256, 0, s>>>(const_cast<T *>(tile) + (long)st * MACRO * (mb + 1), mb,
-                                      winv + (long)st * MACRO * MACRO, nullptr, 0, 0, nullptr);
+                                      winv + (long)st * MACRO * MACRO, nullptr, 0, 0, nullptr, g_ytab);
 }
 
 template <typename T>
@@ -1017,12 +1068,14 @@ void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
   for (int st = 0; st < nbm; ++st) {
     // alpha is applied once to every column block: in the solve of block 0 and as
     // the beta of the first update of blocks > 0
+    // the TRSM of the next panel outranks the trailing update whenever the update yields at
+    // all (the walker enables that only while the panel chain is the critical path)
     k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv,
-                                                  st == 0 ? alpha : T(1));
+                                                  st == 0 ? alpha : T(1), g_ytab);
     const int nc = nbm - 1 - st;
     if (nc > 0)
       k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk,
-                                                          st == 0 ? alpha : T(1));
+                                                          st == 0 ? alpha : T(1), g_ytab);
   }
 }
 
@@ -1090,7 +1143,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int,       \
-                                       const PanelRef &);                                           \
+                                       const PanelRef &, bool);                                     \
   template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int);                       \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
   template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
