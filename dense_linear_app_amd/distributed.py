@@ -168,13 +168,12 @@ class BlockCyclicCholesky:
 
         self.e, self.dist, self.lookahead = engine, dist, lookahead
         self.panel_mode = panel_mode or os.environ.get("CHOLMI_PANEL_MODE", "bcast")
-        # On the ranks that factor / solve panel k+1, hold back the bulk of update k until their
-        # panel kernels are done.  Beside a running trailing update those latency-bound kernels run
-        # 3-5x slower and they are on every rank's critical path, while the
-        # held-back update costs one rank ~1 ms per wave.  Only worth it with several GPUs.
+        # Optional: on the ranks that factor / solve panel k+1, hold back the bulk of update k until
+        # their panel kernels are done.  Off by default: the update kernel already yields its CUs
+        # to the panel chain's workgroups (cooperative CU hand-over), which keeps
+        # the rest of the GPU busy; this switch idles the whole GPU instead (CHOLMI_PANEL_FIRST=1).
         env = os.environ.get("CHOLMI_PANEL_FIRST")
-        self.panel_first = (dist.get_world_size() > 1) if panel_first is None and env is None else (
-            panel_first if panel_first is not None else env == "1")
+        self.panel_first = panel_first if panel_first is not None else (env == "1")
         self._panel_done = None
         assert self.panel_mode in ("bcast", "allgather")
         e = engine
