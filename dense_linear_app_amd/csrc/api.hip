@@ -41,7 +41,7 @@ struct Ctx {
   bool inited = false;
   int device = -1;
   int rank = 0, nranks = 1;
-  hipStream_t s_main = nullptr, s_panel = nullptr;
+  hipStream_t s_main = nullptr, s_panel = nullptr, s_trsm = nullptr;
   void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k)
   size_t winv_bytes = 0;
   int *d_info = nullptr;
@@ -178,11 +178,14 @@ int potrf_full_device(chol_desc *d, void *base) {
   const long bsiz = d->bsizi;
   T *M = reinterpret_cast<T *>(base);
   T *winv = reinterpret_cast<T *>(g.winv);
-  int rc = ensure_events(2 * (size_t)nt + 4 + (g.profiling ? 4 * (size_t)nt : 0));
+  const int nbm_ev = mb / MACRO;
+  int rc = ensure_events(2 * (size_t)nt + 8 + nbm_ev + 4 * (size_t)nt);
   if (rc) return rc;
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
   hipEvent_t ev_start = g.events[2 * nt], ev_stop = g.events[2 * nt + 1], ev_join = g.events[2 * nt + 2];
+  hipEvent_t ev_wave = g.events[2 * nt + 3], ev_trsm = g.events[2 * nt + 4];
+  hipEvent_t *ev_steps = &g.events[2 * nt + 8 + 4 * nt];
   HIPCHECK(hipEventRecord(ev_start, g.s_main));
   HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_start, 0));
   const LocalMat C = local_mat(d, base);
@@ -190,10 +193,15 @@ int potrf_full_device(chol_desc *d, void *base) {
   int upd_launches = 0;
   for (int k = 0; k < nt; ++k) {
     hipEvent_t ev_panel = g.events[2 * k], ev_u1 = g.events[2 * k + 1];
+    HIPCHECK(hipEventRecord(ev_wave, g.s_panel));  // s_panel has waited for U1(k-1): the TRSM stream follows
     // panel stream: POTRF(k,k) then TRSM(i,k), i > k  (C2:510-535)
     T *lkk = M + ((long)k + (long)k * nt) * bsiz;
-    launch_potrf_tile<T>(g.s_panel, lkk, mb, winv, g.d_info, k * mb);
-    launch_trsm_panel<T>(g.s_panel, lkk + bsiz, bsiz, nt - 1 - k, lkk, winv, mb, T(1));
+    // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream
+    HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev_wave, 0));
+    launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv, g.d_info, k * mb, lkk + bsiz, bsiz,
+                              nt - 1 - k);
+    HIPCHECK(hipEventRecord(ev_trsm, g.s_trsm));
+    HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_trsm, 0));
     HIPCHECK(hipEventRecord(ev_panel, g.s_panel));
     // main stream: trailing update (C2:540-560); column k+1 first so that the
     // next panel can start while the rest of the update is still running
@@ -207,9 +215,9 @@ int potrf_full_device(chol_desc *d, void *base) {
       const int u1_lo = d->ge[k + 2 <= nt ? k + 2 : nt], u1_hi = d->ge[k + 1];
       hipEvent_t p0 = nullptr, p1 = nullptr, p2 = nullptr;
       if (g.profiling) {
-        p0 = g.events[2 * nt + 4 + 3 * k];
-        p1 = g.events[2 * nt + 4 + 3 * k + 1];
-        p2 = g.events[2 * nt + 4 + 3 * k + 2];
+        p0 = g.events[2 * nt + 8 + 3 * k];
+        p1 = g.events[2 * nt + 8 + 3 * k + 1];
+        p2 = g.events[2 * nt + 8 + 3 * k + 2];
         HIPCHECK(hipEventRecord(p0, g.s_main));
       }
       // Give CUs to the next panel's guest workgroups only when that panel is on the critical
@@ -247,7 +255,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   if (g.profiling) {
     for (int k = 0; k + 1 < nt; ++k) {
       float a = 0;
-      HIPCHECK(hipEventElapsedTime(&a, g.events[2 * nt + 4 + 3 * k], g.events[2 * nt + 4 + 3 * k + 2]));
+      HIPCHECK(hipEventElapsedTime(&a, g.events[2 * nt + 8 + 3 * k], g.events[2 * nt + 8 + 3 * k + 2]));
       g.update_ms += a;
     }
   }
@@ -401,6 +409,7 @@ int chol_init(int ncpu, int ngpu) {
   HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_main, hipStreamNonBlocking, lo));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
+  HIPCHECK(hipStreamCreateWithPriority(&g.s_trsm, hipStreamNonBlocking, hi));
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
@@ -438,10 +447,11 @@ int chol_finalize(void) {
   cholmi::g_ytab = nullptr;
   (void)hipStreamDestroy(g.s_main);
   (void)hipStreamDestroy(g.s_panel);
+  (void)hipStreamDestroy(g.s_trsm);
   g.winv = nullptr;
   g.d_info = nullptr;
   g.d_acc = nullptr;
-  g.s_main = g.s_panel = nullptr;
+  g.s_main = g.s_panel = g.s_trsm = nullptr;
   g.inited = false;
   return 0;
 }

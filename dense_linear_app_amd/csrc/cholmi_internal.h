@@ -49,6 +49,12 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
 template <typename T>
 void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base);
 
+// POTRF(tile) on stream sp with the TRSM of `ntiles` contiguous tiles pipelined behind it on
+// stream st (ev: mb/MACRO events).  The caller joins both streams.
+template <typename T>
+void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
+                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles);
+
 // winv from an already factored tile
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv);

@@ -1052,6 +1052,35 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
   }
 }
 
+// POTRF of the diagonal tile and TRSM of the panel tiles below it, pipelined over two streams:
+// TRSM step s needs only Winv_s and the blocks L(c,s), c > s, of the diagonal tile, which exist
+// as soon as in-tile step s is done -- so it runs on `st` while the POTRF goes on with step s+1
+// on `sp`.  The chain of a wave shrinks from POTRF + TRSM to about POTRF + one TRSM step.
+// ev: nbm events.  Both streams must be joined by the caller.
+template <typename T>
+void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
+                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles) {
+  const int nbm = mb / MACRO;
+  for (int s = 0; s < nbm; ++s) {
+    const int nr = nbm - 1 - s;
+    k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
+                                       d_info, info_base + s * MACRO, 1, g_dbg, g_ytab);
+    if (nr > 0) k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
+    if (ntiles > 0) {
+      (void)hipEventRecord(ev[s], sp);
+      (void)hipStreamWaitEvent(st, ev[s], 0);
+      k_panel_solve<T><<<ntiles * nbm, 256, 0, st>>>(tiles, bsiz, mb, nbm, 0, s, winv, T(1), g_ytab);
+      if (nr > 0)
+        k_panel_update<T><<<ntiles * nbm * nr, 256, 0, st>>>(tiles, bsiz, mb, nbm, s, lkk, T(1), g_ytab);
+    }
+    if (nr > 0) k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
+  }
+}
+template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
+                                             int *, int, double *, long, int);
+template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
+                                            int, float *, long, int);
+
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
   const int nbm = mb / MACRO;
