@@ -64,6 +64,9 @@ def lib() -> C.CDLL:
         "chol_desc_local_tiles": ([vp, C.POINTER(i), C.POINTER(i)], i),
         "chol_wave_potrf": ([vp, i, vp, vp], i),
         "chol_wave_invert_diag": ([vp, vp, vp], i),
+        "chol_wave_winv_bytes": ([vp], C.c_size_t),
+        "chol_wave_export_winv": ([vp, vp, vp], i),
+        "chol_wave_import_winv": ([vp, vp, vp], i),
         "chol_wave_trsm": ([vp, i, vp, vp], i),
         "chol_wave_update": ([vp, i, i, i, pp, C.POINTER(i), vp], i),
         "chol_get_info": ([C.POINTER(i)], i),

@@ -875,6 +875,27 @@ int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
   return 0;
 }
 
+// Move the 128-block inverses of the current L(k,k) (written by chol_wave_potrf) out of /
+// into the context workspace, so that they can travel with the broadcast of L(k,k) instead of
+// being recomputed on every rank of the process column.
+size_t chol_wave_winv_bytes(chol_desc_t *d) {
+  return d ? (size_t)(d->mbi / MACRO) * MACRO * MACRO * d->esize : 0;
+}
+
+int chol_wave_export_winv(chol_desc_t *d, void *dst, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_export_winv before chol_init");
+  if (!d || !dst) return fail(-1, "wave_export_winv: NULL");
+  HIPCHECK(hipMemcpyAsync(dst, g.winv, chol_wave_winv_bytes(d), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int chol_wave_import_winv(chol_desc_t *d, const void *src, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_import_winv before chol_init");
+  if (!d || !src) return fail(-1, "wave_import_winv: NULL");
+  HIPCHECK(hipMemcpyAsync(g.winv, src, chol_wave_winv_bytes(d), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
 int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_trsm before chol_init");
   if (!d || !lkk) return fail(-1, "wave_trsm: NULL");

@@ -752,9 +752,21 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       ph[1] = tA;
       ph[2] = tB;
     }
-    for (int idx = t; idx < n * n; idx += 256) {
-      const int i = idx & (n - 1), j = idx >> 7;
-      if (i >= j) A[i + (size_t)j * ld] = S[db_idx(i, j)];
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {  // 16 LDS reads in flight, then 16 stores
+      T v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = t + 256 * (16 * pass + u);
+        const int i = idx & (n - 1), j = idx >> 7;
+        v[u] = (i >= j) ? S[db_idx(i, j)] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = t + 256 * (16 * pass + u);
+        const int i = idx & (n - 1), j = idx >> 7;
+        if (i >= j) A[i + (size_t)j * ld] = v[u];
+      }
     }
   }
   if (ph && t == 0) ph[3] = PH_NOW();  // L stored
@@ -819,14 +831,21 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   }
   if (ph && t == 0) ph[5] = PH_NOW();  // phase C done
 #undef PH_NOW
-  for (int idx = t; idx < n * n; idx += 256) {
-    const int i = idx & (n - 1), j = idx >> 7;
-    T v = T(0);
-    if ((i >> 4) == (j >> 4))
-      v = Wd[i >> 4][(i & 15) + (j & 15) * NB];
-    else if (i > j)
-      v = S[db_idx(i, j)];
-    winv[idx] = v;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = t + 256 * (16 * pass + u);
+      const int i = idx & (n - 1), j = idx >> 7;
+      v[u] = T(0);
+      if ((i >> 4) == (j >> 4))
+        v[u] = Wd[i >> 4][(i & 15) + (j & 15) * NB];
+      else if (i > j)
+        v[u] = S[db_idx(i, j)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) winv[t + 256 * (16 * pass + u)] = v[u];
   }
 }
 

@@ -128,6 +128,15 @@ class HipEngine:
     def potrf(self, k: int, lkk, s) -> None:
         self._check("chol_wave_potrf", self._lib.chol_wave_potrf(self.desc.handle, k, lkk.data_ptr(), self._sp(s)))
 
+    def winv_elems(self) -> int:
+        return int(self._lib.chol_wave_winv_bytes(self.desc.handle)) // self.store.element_size()
+
+    def export_winv(self, dst, s) -> None:
+        self._check("chol_wave_export_winv", self._lib.chol_wave_export_winv(self.desc.handle, dst.data_ptr(), self._sp(s)))
+
+    def import_winv(self, src, s) -> None:
+        self._check("chol_wave_import_winv", self._lib.chol_wave_import_winv(self.desc.handle, src.data_ptr(), self._sp(s)))
+
     def invert_diag(self, lkk, s) -> None:
         self._check("chol_wave_invert_diag",
                     self._lib.chol_wave_invert_diag(self.desc.handle, lkk.data_ptr(), self._sp(s)))
@@ -185,7 +194,9 @@ class BlockCyclicCholesky:
             ranks = [pr * e.Q + qc for pr in range(e.P)]
             self.col_groups.append(dist.new_group(ranks=ranks) if e.P > 1 else None)
         maxpart = (e.nt + e.P - 1) // e.P
-        self.lkk_buf = [e.empty_tiles(1) for _ in range(2)]
+        # L(k,k) and, right behind it, the inverses of its 128-blocks: one broadcast per wave
+        self.nwinv = e.winv_elems() if hasattr(e, "winv_elems") else 0
+        self.lkk_buf = [e.empty_tiles(2)[:e.bsiz + self.nwinv] for _ in range(2)]
         if self.panel_mode == "bcast":
             # receive buffers: [parity][process row]
             self.pbuf = [[e.empty_tiles(maxpart) for _ in range(e.P)] for _ in range(2)]
@@ -229,15 +240,24 @@ class BlockCyclicCholesky:
         par = k & 1
         if e.pcol != pc:
             return
+        buf = self.lkk_buf[par]
         if e.prow == pr:
             lkk = e.tiles_view(k // P, k // Q)
             e.potrf(k, lkk, s)
+            if P > 1 and k + 1 < e.nt:
+                # ship the factored tile together with the inverses of its diagonal blocks
+                buf[:e.bsiz].copy_(lkk)
+                if self.nwinv:
+                    e.export_winv(buf[e.bsiz:], s)
         else:
-            lkk = self.lkk_buf[par]
+            lkk = buf[:e.bsiz]
         if P > 1 and k + 1 < e.nt:
-            dist.broadcast(lkk, src=pr * Q + pc, group=self.col_groups[pc])
+            dist.broadcast(buf, src=pr * Q + pc, group=self.col_groups[pc])
             if e.prow != pr:
-                e.invert_diag(lkk, s)
+                if self.nwinv:
+                    e.import_winv(buf[e.bsiz:], s)
+                else:
+                    e.invert_diag(lkk, s)
         if k + 1 < e.nt:
             e.trsm(k, lkk, s)
         if self.panel_first:

@@ -173,6 +173,11 @@ int chol_wave_potrf(chol_desc_t *desc, int k, void *lkk, void *stream);
 /* After the diagonal tile arrived by broadcast on a non-owner: rebuild the
  * 128-block inverses from the received L(k,k). */
 int chol_wave_invert_diag(chol_desc_t *desc, void *lkk, void *stream);
+/* The 128-block inverses that chol_wave_potrf left in the context, as bytes to ship beside
+ * L(k,k) (export on the owner, import on the receivers) instead of chol_wave_invert_diag. */
+size_t chol_wave_winv_bytes(chol_desc_t *desc);
+int chol_wave_export_winv(chol_desc_t *desc, void *dst, void *stream);
+int chol_wave_import_winv(chol_desc_t *desc, const void *src, void *stream);
 /* TRSM of this process's tiles (i,k), i > k, against `lkk`. */
 int chol_wave_trsm(chol_desc_t *desc, int k, const void *lkk, void *stream);
 /* Trailing update of this process's tiles (i,j), j in [jlo, jhi), i >= j, i > k,
