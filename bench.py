@@ -52,8 +52,22 @@ def cpu_baseline(N: int, B: int, seed: int) -> dict:
     t0 = time.perf_counter()
     info = orc.tiled_potrf(T, N // B, B, nthreads)
     dt = time.perf_counter() - t0
-    return {"value": round(N ** 3 / 3.0 / dt / 1e12, 5), "unit": "TFLOP/s", "cores": nthreads, "kind": "port",
-            "sample": f"one full factorisation N={N} tile={B} fp64 plgsy(seed={seed}), {dt:.2f} s, info={info}"}
+    out = {"value": round(N ** 3 / 3.0 / dt / 1e12, 5), "unit": "TFLOP/s", "cores": nthreads, "kind": "port",
+           "sample": f"one full factorisation N={N} tile={B} fp64 plgsy(seed={seed}), {dt:.2f} s, info={info}"}
+    # secondary, clearly labelled: the vendor LAPACK that ships with torch, same N, same threads
+    try:
+        import torch
+
+        torch.set_num_threads(nthreads)
+        A = torch.from_numpy(orc.tile_to_lapack(orc.plgsy_tiles(N // B, B, float(N), seed), N, B))
+        t0 = time.perf_counter()
+        torch.linalg.cholesky(A)
+        dt2 = time.perf_counter() - t0
+        out["vendor_lapack"] = {"value": round(N ** 3 / 3.0 / dt2 / 1e12, 5), "unit": "TFLOP/s",
+                                "what": f"torch.linalg.cholesky on CPU, N={N}, {nthreads} threads, {dt2:.2f} s"}
+    except Exception as e:  # never let the side line break the bench
+        out["vendor_lapack"] = {"error": str(e)[:80]}
+    return out
 
 
 def load_pmc_traffic():
