@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         "chol_tile_upload": ([vp, i, i, vp], i),
         "chol_tile_download": ([vp, i, i, vp], i),
         "chol_residual_plgsy": ([vp, d, u64, C.POINTER(d)], i),
+        "chol_residual_plgsy_inf": ([vp, d, u64, C.POINTER(d)], i),
         "chol_make_spd_like_chameleon": ([vp, i, i, d, C.c_char, u64], None),
         "chol_enforce_strict_diag_dominance": ([vp, i, i, d], None),
         "chol_extract_block": ([vp, i, i, i, i, i, vp], None),

@@ -184,6 +184,13 @@ def residual_plgsy(L: Desc, bump: float, seed: int) -> float:
     return r.value
 
 
+def residual_plgsy_inf(L: Desc, bump: float, seed: int) -> float:
+    """||A - L L^T||_inf / ||A||_inf: the number V6:86 prints, computed correctly on the device."""
+    r = C.c_double()
+    check("chol_residual_plgsy_inf", lib().chol_residual_plgsy_inf(L.handle, float(bump), int(seed), C.byref(r)))
+    return r.value
+
+
 def last_potrf_stats() -> dict:
     t, u, f = C.c_double(), C.c_double(), C.c_double()
     n = C.c_int()
@@ -210,4 +217,4 @@ def set_profiling(on: bool) -> None:
 
 
 __all__ = [n for n in dir() if n.startswith(("CHAMELEON_", "Cham"))] + [
-    "Desc", "CholmiError", "residual_plgsy", "last_potrf_stats", "set_profiling", "set_device", "set_rank"]
+    "Desc", "CholmiError", "residual_plgsy", "residual_plgsy_inf", "last_potrf_stats", "set_profiling", "set_device", "set_rank"]

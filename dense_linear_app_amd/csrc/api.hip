@@ -719,24 +719,51 @@ int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
   return 0;
 }
 
-int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel) {
+static int residual_common(chol_desc_t *L, double bump, unsigned long long seed, double *rel_fro,
+                           double *rel_inf) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "residual before chol_init");
-  if (!L || !rel) return fail(-1, "residual: NULL");
+  if (!L || (!rel_fro && !rel_inf)) return fail(-1, "residual: NULL");
   if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mbi % MACRO)
     return fail(CHOL_ERR_NOT_SUPPORTED, "residual: single-process device-resident square tiled matrix only");
   std::lock_guard<std::mutex> lk(g_mu);
+  const long n = L->lm;
+  double *rows = nullptr;
+  if (rel_inf) {
+    HIPCHECK(hipMalloc(&rows, 2 * (size_t)n * sizeof(double)));
+    HIPCHECK(hipMemsetAsync(rows, 0, 2 * (size_t)n * sizeof(double), g.s_main));
+  }
   HIPCHECK(hipMemsetAsync(g.d_acc, 0, 2 * sizeof(double), g.s_main));
   if (L->dtype == CHOL_REAL_DOUBLE)
     launch_residual<double>(g.s_main, reinterpret_cast<const double *>(L->mat), L->nt, L->mbi, bump, seed,
-                            g.d_acc, L->mb, (long)L->lm);
+                            g.d_acc, L->mb, n, rows);
   else
     launch_residual<float>(g.s_main, reinterpret_cast<const float *>(L->mat), L->nt, L->mbi, bump, seed,
-                           g.d_acc, L->mb, (long)L->lm);
+                           g.d_acc, L->mb, n, rows);
   double h[2];
   HIPCHECK(hipMemcpyAsync(h, g.d_acc, sizeof h, hipMemcpyDeviceToHost, g.s_main));
   HIPCHECK(hipStreamSynchronize(g.s_main));
-  *rel = sqrt(h[0]) / sqrt(h[1]);
+  if (rel_fro) *rel_fro = sqrt(h[0]) / sqrt(h[1]);
+  if (rel_inf) {
+    std::vector<double> hr(2 * (size_t)n);
+    hipError_t e = hipMemcpy(hr.data(), rows, hr.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(rows);
+    if (e != hipSuccess) return fail_hip(e, "residual row sums", __LINE__);
+    double rmax = 0, amax = 0;
+    for (long r = 0; r < n; ++r) {
+      rmax = std::max(rmax, hr[r]);
+      amax = std::max(amax, hr[n + r]);
+    }
+    *rel_inf = rmax / (amax > 0 ? amax : 1.0);  // V6:84
+  }
   return 0;
+}
+
+int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel) {
+  return residual_common(L, bump, seed, rel, nullptr);
+}
+
+int chol_residual_plgsy_inf(chol_desc_t *L, double bump, unsigned long long seed, double *rel_inf) {
+  return residual_common(L, bump, seed, nullptr, rel_inf);
 }
 
 // ---------------------------------------------------------------- instrumentation

@@ -77,7 +77,8 @@ void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol,
 // counted twice) into acc[0], acc[1] (device doubles).  Single process only.
 template <typename T>
 void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
-                     unsigned long long seed, double *d_acc, int mbu, long nglob);
+                     unsigned long long seed, double *d_acc, int mbu, long nglob,
+                     double *rowsum = nullptr);  // rowsum: 2*nglob doubles (|R| rows, then |A| rows), zeroed
 
 // pad helpers for the staged 1-tile path: dst is ldp x ldp (zeroed), identity on
 // the padded part of the diagonal when `unit_pad`.

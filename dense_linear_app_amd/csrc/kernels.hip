@@ -923,9 +923,11 @@ __global__ __launch_bounds__(256) void k_plgsy(LocalMat A, int lnt, int prow, in
 template <typename T>
 __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int Nb, int mb, int nbm,
                                                      double bump, unsigned long long seed,
-                                                     double *acc_out, int mbu, long nglob) {
+                                                     double *acc_out, int mbu, long nglob,
+                                                     double *rowsum) {
   __shared__ Smem<T> sm;
   __shared__ double red[2][4];
+  __shared__ double rs[4][MACRO];  // |R| and |A| sums: by block row (0,1) and by block column (2,3)
   const int MT = nbm * nbm;
   const int tix = blockIdx.x / MT, macro = blockIdx.x % MT;
   // tix -> (i >= j), row-major over the lower triangle
@@ -950,6 +952,10 @@ __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int N
   }
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
   double num = 0.0, den = 0.0;
+  if (rowsum) {
+    for (int q = t; q < 4 * MACRO; q += 256) (&rs[0][0])[q] = 0.0;
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -966,7 +972,30 @@ __global__ __launch_bounds__(256) void k_residual(const T *__restrict__ L, int N
         const double wgt = (gi == gj) ? 1.0 : 2.0;
         num += wgt * d * d;
         den += wgt * aij * aij;
+        if (rowsum) {  // infinity norm: row sums of |R| and |A|; (gi,gj), gi > gj, also stands for (gj,gi)
+          const int rl = ii - mi * MACRO, cl = jj - mj * MACRO;
+          atomicAdd(&rs[0][rl], fabs(d));
+          atomicAdd(&rs[1][rl], fabs(aij));
+          if (gi != gj) {
+            atomicAdd(&rs[2][cl], fabs(d));
+            atomicAdd(&rs[3][cl], fabs(aij));
+          }
+        }
       }
+  if (rowsum) {
+    __syncthreads();
+    for (int q = t; q < MACRO; q += 256) {
+      const long gr = (long)i * mbu + mi * MACRO + q, gc = (long)j * mbu + mj * MACRO + q;
+      if (mi * MACRO + q < mbu && gr < nglob) {
+        atomicAdd(&rowsum[gr], rs[0][q]);
+        atomicAdd(&rowsum[nglob + gr], rs[1][q]);
+      }
+      if (mj * MACRO + q < mbu && gc < nglob) {
+        atomicAdd(&rowsum[gc], rs[2][q]);
+        atomicAdd(&rowsum[nglob + gc], rs[3][q]);
+      }
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) {
     num += __shfl_down(num, o, 64);
     den += __shfl_down(den, o, 64);
@@ -1142,10 +1171,10 @@ void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol,
 
 template <typename T>
 void launch_residual(hipStream_t s, const T *Lbase, int Nb, int mb, double bump,
-                     unsigned long long seed, double *d_acc, int mbu, long nglob) {
+                     unsigned long long seed, double *d_acc, int mbu, long nglob, double *rowsum) {
   const int nbm = mb / MACRO;
   const long ntile = (long)Nb * (Nb + 1) / 2;
-  k_residual<T><<<dim3((unsigned)(ntile * nbm * nbm)), 256, 0, s>>>(Lbase, Nb, mb, nbm, bump, seed, d_acc, mbu, nglob);
+  k_residual<T><<<dim3((unsigned)(ntile * nbm * nbm)), 256, 0, s>>>(Lbase, Nb, mb, nbm, bump, seed, d_acc, mbu, nglob, rowsum);
 }
 
 template <typename T>
@@ -1199,7 +1228,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
   template void launch_plgsy<T>(hipStream_t, const LocalMat &, int, int, int, double,               \
                                 unsigned long long, int, long);                                     \
   template void launch_residual<T>(hipStream_t, const T *, int, int, double, unsigned long long,    \
-                                   double *, int, long);                                            \
+                                   double *, int, long, double *);                                  \
   template void launch_pad_identity<T>(hipStream_t, T *, int, int);
 INSTANTIATE(double)
 INSTANTIATE(float)

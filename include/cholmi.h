@@ -128,6 +128,8 @@ int chol_tile_download(chol_desc_t *desc, int I, int J, void *host_tile);
 /* ||tril(L) tril(L)^T - A||_F / ||A||_F with A regenerated by the plgsy rule
  * (the check V6:72-87 intended).  L = factored descriptor. */
 int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel);
+/* The quantity v6_test.c:72-86 prints, computed correctly: ||A - L L^T||_inf / ||A||_inf. */
+int chol_residual_plgsy_inf(chol_desc_t *L, double bump, unsigned long long seed, double *rel_inf);
 
 /* ---- client-side host helpers (pure host code, usable without a GPU) ------ */
 /* make_spd_like_chameleon C2:224-252 + enforce_strict_diag_dominance C2:255-264 */

@@ -168,3 +168,23 @@ def test_full_potrf_upper(cham, orc, N, B):
     M[N - 5, N - 5] = -2.0
     d.from_lapack(M)
     assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, d) == N - 4
+
+
+def test_residual_inf_norm_matches_numpy(cham):
+    """chol_residual_plgsy_inf = ||A - L L^T||_inf / ||A||_inf (v6_test.c:72-86, done right)."""
+    ch = cham
+    for N, B in ((1024, 256), (1000, 192)):
+        d = full_desc(ch, N, B)
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 11)
+        A = d.to_lapack()
+        assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+        L = np.tril(d.to_lapack())
+        t = d.download_tile(1, 0)
+        t[3, 4] += 1e-6  # make the residual large enough to compare meaningfully
+        d.upload_tile(1, 0, t)
+        L[B + 3, 4] += 1e-6
+        R = L @ L.T - A
+        ref_inf = np.abs(R).sum(axis=1).max() / np.abs(A).sum(axis=1).max()
+        ref_fro = np.linalg.norm(R) / np.linalg.norm(A)
+        assert abs(ch.residual_plgsy_inf(d, float(N), 11) - ref_inf) <= 1e-3 * ref_inf
+        assert abs(ch.residual_plgsy(d, float(N), 11) - ref_fro) <= 1e-3 * ref_fro
