@@ -70,7 +70,8 @@ def _run(world, N, B, lookahead=True, bad=None, mode="bcast"):
 
 @pytest.mark.parametrize("world,lookahead,mode", [(2, True, "bcast"), (2, False, "bcast"), (4, True, "bcast"),
                                                   (2, True, "allgather"), (4, True, "allgather"),
-                                                  (4, False, "allgather")])
+                                                  (4, False, "allgather"), (8, True, "bcast"),
+                                                  (8, True, "allgather"), (6, True, "bcast")])
 def test_block_cyclic_factorisation_matches_oracle(world, lookahead, mode):
     from oracle import oracle as orc
 
