@@ -47,6 +47,10 @@ def lib() -> C.CDLL:
         "chol_syrk_tile": ([i, i, d, vp, d, vp], i),
         "chol_gemm_tile": ([i, i, d, vp, vp, d, vp], i),
         "chol_plgsy_tile": ([d, i, vp, u64], i),
+        "chol_lacpy_tile": ([i, vp, vp], i),
+        "chol_lange_tile": ([i, vp, C.POINTER(d)], i),
+        "chol_lauum_tile": ([i, vp], i),
+        "chol_geadd_tile": ([i, d, vp, d, vp], i),
         "chol_lapack_to_tile": ([vp, i, vp], i),
         "chol_tile_to_lapack": ([vp, vp, i], i),
         "chol_tile_upload": ([vp, i, i, vp], i),

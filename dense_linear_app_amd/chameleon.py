@@ -22,7 +22,8 @@ from ._lib import CholmiError, check, lib
 
 ChamRealFloat, ChamRealDouble = 2, 3
 ChamNoTrans, ChamTrans = 111, 112
-ChamUpper, ChamLower = 121, 122
+ChamUpper, ChamLower, ChamUpperLower = 121, 122, 123
+ChamOneNorm, ChamFrobeniusNorm, ChamInfNorm, ChamMaxNorm = 171, 174, 175, 177
 ChamNonUnit, ChamUnit = 131, 132
 ChamLeft, ChamRight = 141, 142
 
@@ -175,6 +176,35 @@ def CHAMELEON_dplgsy_Tile(bump: float, uplo: int, A: Desc, seed: int) -> int:
 
 
 CHAMELEON_splgsy_Tile = CHAMELEON_dplgsy_Tile
+
+
+# -- the validation block of the reference driver (V6:51, 72-86)
+def CHAMELEON_dlacpy_Tile(uplo: int, A: Desc, B: Desc) -> int:
+    """V6:51, 79: B <- A on the `uplo` part (ChamUpperLower: everything)."""
+    return check("chol_lacpy_tile", lib().chol_lacpy_tile(uplo, A.handle, B.handle))
+
+
+def CHAMELEON_dlange_Tile(norm: int, A: Desc) -> float:
+    """V6:74, 85.  Returns the norm, as Chameleon does."""
+    r = C.c_double()
+    check("chol_lange_tile", lib().chol_lange_tile(norm, A.handle, C.byref(r)))
+    return r.value
+
+
+def CHAMELEON_dlauum_Tile(uplo: int, A: Desc) -> int:
+    """V6:80: tril(A) <- tril(L^T L) with L = tril(A)  (ChamLower)."""
+    return check("chol_lauum_tile", lib().chol_lauum_tile(uplo, A.handle))
+
+
+def CHAMELEON_dgeadd_Tile(trans: int, alpha: float, A: Desc, beta: float, B: Desc) -> int:
+    """V6:83: B <- alpha A + beta B."""
+    return check("chol_geadd_tile", lib().chol_geadd_tile(trans, float(alpha), A.handle, float(beta), B.handle))
+
+
+CHAMELEON_slacpy_Tile = CHAMELEON_dlacpy_Tile
+CHAMELEON_slange_Tile = CHAMELEON_dlange_Tile
+CHAMELEON_slauum_Tile = CHAMELEON_dlauum_Tile
+CHAMELEON_sgeadd_Tile = CHAMELEON_dgeadd_Tile
 
 
 def residual_plgsy(L: Desc, bump: float, seed: int) -> float:

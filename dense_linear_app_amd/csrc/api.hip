@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -524,9 +525,12 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     if (d->padded) {  // zero everywhere, identity on the diagonal tiles' diagonals
       const LocalMat Lm = local_mat(d, d->mat);
       if (dtype == CHOL_REAL_DOUBLE)
-        launch_plgsy<double>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0);
+        launch_plgsy<double>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
       else
-        launch_plgsy<float>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0);
+        launch_plgsy<float>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
+      (void)hipStreamSynchronize(g.s_main);
+    } else {  // library-owned storage starts at zero (tiles a one-sided dplgsy does not touch)
+      (void)hipMemsetAsync(d->mat, 0, bytes, g.s_main);
       (void)hipStreamSynchronize(g.s_main);
     }
   }
@@ -648,7 +652,8 @@ int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_de
 // ---------------------------------------------------------------- generator / layout / residual
 int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "plgsy_tile before chol_init");
-  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-2, "plgsy_tile: uplo");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-2, "plgsy_tile: uplo");
+  const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
   if (!A) return fail(-3, "plgsy_tile: NULL descriptor");
   if (!A->on_device) return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: descriptor must be device-resident");
   if (A->mt == 1 && A->nt == 1 && (A->m != A->mb || A->n != A->nb))
@@ -656,10 +661,134 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
   std::lock_guard<std::mutex> lk(g_mu);
   const LocalMat L = local_mat(A, A->mat);
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm);
+    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
   else
-    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm);
+    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
   HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+// ---------------------------------------------------------------- V6 validation block
+static int resident_whole(const char *what, const chol_desc *d) {
+  static char buf[160];
+  const char *why = nullptr;
+  if (!d) why = "NULL descriptor";
+  else if (!d->on_device) why = "descriptor must be device-resident";
+  else if (d->p * d->q != 1) why = "distributed descriptor";
+  else if (d->mb != d->nb) why = "tiles must be square";
+  if (!why) return 0;
+  snprintf(buf, sizeof buf, "%s: %s", what, why);
+  return fail(d ? CHOL_ERR_NOT_SUPPORTED : -2, buf);
+}
+static bool same_geometry(const chol_desc *a, const chol_desc *b) {
+  return a->dtype == b->dtype && a->mb == b->mb && a->nb == b->nb && a->lm == b->lm && a->ln == b->ln &&
+         a->mbi == b->mbi && a->lmt == b->lmt && a->lnt == b->lnt;
+}
+static TileGeo geo_of(const chol_desc *d) {
+  TileGeo g;
+  g.lmt = d->lmt;
+  g.lnt = d->lnt;
+  g.mbs = d->mbi;
+  g.mbu = d->mb;
+  g.m = d->lm;
+  g.n = d->ln;
+  return g;
+}
+
+int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lacpy_tile before chol_init");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-1, "lacpy_tile: uplo");
+  int rc = resident_whole("lacpy_tile", A);
+  if (rc) return rc;
+  rc = resident_whole("lacpy_tile", B);
+  if (rc) return rc;
+  if (!same_geometry(A, B)) return fail(-3, "lacpy_tile: descriptors differ in shape, tiling or type");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
+  if (A->dtype == CHOL_REAL_DOUBLE)
+    launch_lacpy<double>(g.s_main, geo_of(A), side, (const double *)A->mat, (double *)B->mat);
+  else
+    launch_lacpy<float>(g.s_main, geo_of(A), side, (const float *)A->mat, (float *)B->mat);
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *B) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "geadd_tile before chol_init");
+  if (trans != CHOL_NOTRANS) return fail(CHOL_ERR_NOT_SUPPORTED, "geadd_tile: only ChamNoTrans (V6:83)");
+  int rc = resident_whole("geadd_tile", A);
+  if (rc) return rc;
+  rc = resident_whole("geadd_tile", B);
+  if (rc) return rc;
+  if (!same_geometry(A, B)) return fail(-5, "geadd_tile: descriptors differ in shape, tiling or type");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (A->dtype == CHOL_REAL_DOUBLE)
+    launch_geadd<double>(g.s_main, geo_of(A), alpha, (const double *)A->mat, beta, (double *)B->mat);
+  else
+    launch_geadd<float>(g.s_main, geo_of(A), alpha, (const float *)A->mat, beta, (float *)B->mat);
+  HIPCHECK(hipStreamSynchronize(g.s_main));
+  return 0;
+}
+
+int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lange_tile before chol_init");
+  if (!value) return fail(-3, "lange_tile: NULL value");
+  int kind;
+  switch (norm) {
+    case CHOL_MAX_NORM: kind = 0; break;
+    case CHOL_ONE_NORM: kind = 1; break;
+    case CHOL_INF_NORM: kind = 2; break;
+    case CHOL_FROBENIUS_NORM: kind = 3; break;
+    default: return fail(-1, "lange_tile: norm");
+  }
+  int rc = resident_whole("lange_tile", A);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const TileGeo ge = geo_of(A);
+  double *work = nullptr;
+  HIPCHECK(hipMalloc(&work, (size_t)(std::max(ge.m, ge.n) + 2) * sizeof(double)));
+  if (A->dtype == CHOL_REAL_DOUBLE)
+    launch_lange<double>(g.s_main, ge, kind, (const double *)A->mat, work);
+  else
+    launch_lange<float>(g.s_main, ge, kind, (const float *)A->mat, work);
+  double v = 0;
+  hipError_t e = hipMemcpyAsync(&v, work, sizeof(double), hipMemcpyDeviceToHost, g.s_main);
+  if (e == hipSuccess) e = hipStreamSynchronize(g.s_main);
+  (void)hipFree(work);
+  if (e != hipSuccess) return fail_hip(e, "lange_tile", __LINE__);
+  *value = kind == 3 ? std::sqrt(v) : v;
+  return 0;
+}
+
+int chol_lauum_tile(int uplo, chol_desc_t *A) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lauum_tile before chol_init");
+  if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "lauum_tile: only ChamLower (V6:80)");
+  int rc = resident_whole("lauum_tile", A);
+  if (rc) return rc;
+  if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "lauum_tile: matrix is not square");
+  if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "lauum_tile: stored tile edge must be a multiple of 64");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t bytes = (size_t)A->mt * A->nt * A->bsizi * A->esize;
+  void *tmp = nullptr;
+  if (hipMalloc(&tmp, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CHOL_ERR_OUT_OF_MEMORY, "lauum_tile: scratch allocation failed");
+  }
+  // stored-image geometry: copy every stored position of the lower part back (padding included)
+  TileGeo ge = geo_of(A);
+  ge.mbu = ge.mbs;
+  ge.m = (long)ge.lmt * ge.mbs;
+  ge.n = (long)ge.lnt * ge.mbs;
+  if (A->dtype == CHOL_REAL_DOUBLE) {
+    launch_lauum_lower<double>(g.s_main, (const double *)A->mat, (double *)tmp, A->nt, A->mbi);
+    launch_lacpy<double>(g.s_main, ge, 1, (const double *)tmp, (double *)A->mat);
+  } else {
+    launch_lauum_lower<float>(g.s_main, (const float *)A->mat, (float *)tmp, A->nt, A->mbi);
+    launch_lacpy<float>(g.s_main, ge, 1, (const float *)tmp, (float *)A->mat);
+  }
+  hipError_t e = hipStreamSynchronize(g.s_main);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail_hip(e, "lauum_tile", __LINE__);
   return 0;
 }
 

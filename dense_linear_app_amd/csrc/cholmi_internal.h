@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <vector>
 
 namespace cholmi {
@@ -71,7 +72,7 @@ void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T 
 
 template <typename T>
 void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
-                  unsigned long long seed, int mbu, long nglob);
+                  unsigned long long seed, int mbu, long nglob, int side);
 
 // accumulates sum((LL^T - A)^2) and sum(A^2) over the lower triangle (strict part
 // counted twice) into acc[0], acc[1] (device doubles).  Single process only.
@@ -88,6 +89,25 @@ void launch_pad_identity(hipStream_t s, T *dst, int n, int ldp);
 // in-place transpose of a whole nt x nt tile matrix (mb multiple of 64)
 template <typename T>
 void launch_transpose_inplace(hipStream_t s, T *M, int nt, int mb);
+
+// ---- launchers (verify_ops.hip): the driver's validation block, v6_test.c:51, 74-85 ----
+// Geometry of a single-process stored tile image: lmt x lnt tiles of mbs x mbs elements, of
+// which the caller's tile is the leading mbu x mbu part; the matrix is m x n.
+struct TileGeo {
+  int lmt, lnt, mbs, mbu;
+  long m, n;
+};
+// side: 0 all, 1 on or below the diagonal, 2 on or above
+template <typename T>
+void launch_lacpy(hipStream_t s, const TileGeo &g, int side, const T *A, T *B);
+template <typename T>
+void launch_geadd(hipStream_t s, const TileGeo &g, double alpha, const T *A, double beta, T *B);
+// work: max(m, n) + 2 device doubles; result in work[0] (kind 0 max, 1 one, 2 inf, 3 sum of squares)
+template <typename T>
+void launch_lange(hipStream_t s, const TileGeo &g, int kind, const T *A, double *work);
+// out(I,J) = sum_{K>=I} L(K,I)^T L(K,J), I >= J (lower part only; out != L)
+template <typename T>
+void launch_lauum_lower(hipStream_t s, const T *L, T *out, int nt, int mbs);
 
 // register-only MFMA stream (blocks x 256 threads, 16 MFMA per wave per iteration)
 template <typename T>

@@ -49,10 +49,15 @@ enum {
   CHOL_TRANS = 112,     /* ChamTrans   */
   CHOL_UPPER = 121,     /* ChamUpper   */
   CHOL_LOWER = 122,     /* ChamLower   */
+  CHOL_UPPER_LOWER = 123, /* ChamUpperLower (V6:51) */
   CHOL_NONUNIT = 131,   /* ChamNonUnit */
   CHOL_UNIT = 132,      /* ChamUnit    */
   CHOL_LEFT = 141,      /* ChamLeft    */
-  CHOL_RIGHT = 142      /* ChamRight   */
+  CHOL_RIGHT = 142,     /* ChamRight   */
+  CHOL_ONE_NORM = 171,       /* ChamOneNorm       */
+  CHOL_FROBENIUS_NORM = 174, /* ChamFrobeniusNorm */
+  CHOL_INF_NORM = 175,       /* ChamInfNorm (V6:74) */
+  CHOL_MAX_NORM = 177        /* ChamMaxNorm       */
 };
 
 enum {
@@ -110,11 +115,26 @@ int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double bet
 int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
                    double beta, chol_desc_t *C);
 
-/* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: fill a symmetric matrix with
- * pseudo-random off-diagonal entries in [-0.5, 0.5) and `bump` added to the
- * diagonal, directly in tile layout on the device.  Values depend only on
- * (global row, global col, seed): independent of tile size and process grid. */
+/* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: Chameleon's generator (published
+ * core_dplgsy: 64-bit LCG with jump-ahead, entry (i,j), i >= j, = 0.5 - ran_{i + j*m} / 2^64,
+ * symmetric, `bump` added to the diagonal), directly in tile layout on the device.  Values
+ * depend only on (global row, global col, matrix order m, seed): independent of tile size
+ * and process grid.  uplo = ChamLower / ChamUpper: the tiles on that side and the diagonal
+ * tiles in full, the other tiles are left as they are (Chameleon's rule; library-allocated
+ * storage starts at zero); ChamUpperLower: every tile. */
 int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed);
+
+/* The validation block of the reference driver, V6:51 and V6:72-86, on device-resident
+ * single-process descriptors of identical geometry:
+ *   CHAMELEON_dlacpy_Tile(uplo, A, B)            V6:51, 79   B <- A on the uplo part
+ *   CHAMELEON_dlange_Tile(norm, A)               V6:74, 85   *value <- the norm
+ *   CHAMELEON_dlauum_Tile(ChamLower, A)          V6:80       tril(A) <- tril(L^T L), L = tril(A)
+ *   CHAMELEON_dgeadd_Tile(ChamNoTrans, a, A, b, B) V6:83     B <- a A + b B
+ * (s-precision by descriptor dtype).  dlauum takes a scratch copy of the matrix. */
+int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B);
+int chol_lange_tile(int norm, chol_desc_t *A, double *value);
+int chol_lauum_tile(int uplo, chol_desc_t *A);
+int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *B);
 
 /* CHAMELEON_Lapack_to_Tile / Tile_to_Lapack equivalents (host LAPACK layout
  * <-> descriptor storage); single-process descriptors only. */

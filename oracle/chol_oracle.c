@@ -137,28 +137,64 @@ ORC_API void orc_extract_block(const double *A, int N, int LDA, int B, int bi, i
 }
 
 /* ------------------------------------------------------------------------ */
-/* Throughput-run generator: CHAMELEON_dplgsy_Tile stand-in    */
-/* (V6:46, bump = N, seed 42).  Counter-based, so any tile of any layout on  */
-/* any number of GPUs sees the same matrix.  The product's device kernel     */
-/* (csrc/cholmi_gen.hip) must produce exactly these bits.                    */
+/* CHAMELEON_dplgsy_Tile (V6:46, bump = N, seed 42 from BN:131).              */
+/* Chameleon is a third-party dependency cloned at unpinned HEAD             */
+/* (Dockerfile.worker.v4:60) and is not under /root/reference; what follows   */
+/* restates its published generator (coreblas core_dplgsy, inherited from     */
+/* PLASMA): a 64-bit LCG  ran <- a*ran + c  (a = 6364136223846793005, c = 1)  */
+/* addressed by jump-ahead.  The entry at (i, j), i >= j, of an order-bigM    */
+/* matrix is  0.5 - ran_n * 2^-64  with ran_n the state n = i + j*bigM steps  */
+/* after `seed` (ran_0 = seed); the matrix is symmetric and `bump` is added   */
+/* to the diagonal.  Counter-based, so any tile of any layout on any number   */
+/* of GPUs sees the same matrix.                                              */
+/* PINNED by the reference's own recorded outputs: the 35 rel_error values of */
+/* Cholesky_chameleon_VM/cho/benchmark_results_plots/bench.csv (col 12) are   */
+/* reproduced to all 3 printed digits by this generator + the literal V6      */
+/* validation sequence (tests/test_oracle_golden.py, tests/golden/            */
+/* reference_vm_rel_error.json).  The product's k_plgsy must produce exactly  */
+/* these bits.                                                                */
 /* ------------------------------------------------------------------------ */
-static inline uint64_t splitmix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
+#define ORC_LCG_A 6364136223846793005ULL
+#define ORC_LCG_C 1ULL
+#define ORC_LCG_MUL 5.4210108624275222e-20 /* 2^-64 */
+
+ORC_API uint64_t orc_lcg_jump(uint64_t n, uint64_t seed) {
+  uint64_t a_k = ORC_LCG_A, c_k = ORC_LCG_C, ran = seed;
+  for (; n; n >>= 1) {
+    if (n & 1) ran = a_k * ran + c_k;
+    c_k *= (a_k + 1);
+    a_k *= a_k;
+  }
+  return ran;
 }
 
-ORC_API double orc_plgsy_entry(double bump, uint64_t seed, int64_t i, int64_t j) {
-  uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
-  uint64_t h = splitmix64(splitmix64(seed ^ (hi << 32 | lo)) + lo);
-  double v = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+ORC_API double orc_plgsy_entry(double bump, uint64_t seed, int64_t bigM, int64_t i, int64_t j) {
+  const uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+  const uint64_t ran = orc_lcg_jump(hi + lo * (uint64_t)bigM, seed);
+  const double v = 0.5f - (double)ran * ORC_LCG_MUL;
   return (i == j) ? v + bump : v;
 }
 
+/* Full symmetric N x N column-major matrix: one jump per column, then the LCG
+ * runs down the column (this is how the published generator walks a tile). */
+ORC_API void orc_plgsy_matrix(double *A, int N, int lda, double bump, uint64_t seed) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int j = 0; j < N; ++j) {
+    uint64_t ran = orc_lcg_jump((uint64_t)j + (uint64_t)j * (uint64_t)N, seed);
+    for (int i = j; i < N; ++i) {
+      const double v = 0.5f - (double)ran * ORC_LCG_MUL;
+      ran = ORC_LCG_A * ran + ORC_LCG_C;
+      A[(size_t)i + (size_t)j * lda] = v;
+      A[(size_t)j + (size_t)i * lda] = v;
+    }
+    A[(size_t)j + (size_t)j * lda] += bump;
+  }
+}
+
 /* Fill a tile-layout matrix (tile (I,J) at ((I + J*Nb) * B*B), column-major
- * inside, ld = B: the Chameleon descriptor layout of V6:44 with lm=ln=N). */
+ * inside, ld = B: the Chameleon descriptor layout of V6:44 with lm=ln=N=Nb*B). */
 ORC_API void orc_plgsy_tiles(double *T, int Nb, int B, double bump, uint64_t seed) {
+  const int64_t N = (int64_t)Nb * B;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int J = 0; J < Nb; ++J)
     for (int I = 0; I < Nb; ++I) {
@@ -166,7 +202,7 @@ ORC_API void orc_plgsy_tiles(double *T, int Nb, int B, double bump, uint64_t see
       for (int jj = 0; jj < B; ++jj)
         for (int ii = 0; ii < B; ++ii)
           t[ii + (size_t)jj * B] =
-              orc_plgsy_entry(bump, seed, (int64_t)I * B + ii, (int64_t)J * B + jj);
+              orc_plgsy_entry(bump, seed, N, (int64_t)I * B + ii, (int64_t)J * B + jj);
     }
 }
 

@@ -49,8 +49,11 @@ def lib() -> C.CDLL:
         L.orc_make_spd_like_chameleon.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_char, C.c_uint64]
         L.orc_enforce_strict_diag_dominance.argtypes = [_dp, C.c_int, C.c_int, C.c_double]
         L.orc_extract_block.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
-        L.orc_plgsy_entry.argtypes = [C.c_double, C.c_uint64, C.c_int64, C.c_int64]
+        L.orc_lcg_jump.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_lcg_jump.restype = C.c_uint64
+        L.orc_plgsy_entry.argtypes = [C.c_double, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
         L.orc_plgsy_entry.restype = C.c_double
+        L.orc_plgsy_matrix.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_plgsy_tiles.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_dgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                    C.c_double, _dp, C.c_int]
@@ -105,8 +108,21 @@ def extract_block(A: np.ndarray, B: int, bi: int, bj: int) -> np.ndarray:
     return blk
 
 
-def plgsy_entry(bump: float, seed: int, i: int, j: int) -> float:
-    return lib().orc_plgsy_entry(bump, seed, i, j)
+def lcg_jump(n: int, seed: int) -> int:
+    """State of Chameleon's plgsy LCG n steps after `seed` (published core_dplgsy jump-ahead)."""
+    return int(lib().orc_lcg_jump(n, seed))
+
+
+def plgsy_entry(bump: float, seed: int, N: int, i: int, j: int) -> float:
+    """Entry (i, j) of the order-N matrix CHAMELEON_dplgsy_Tile(bump, ., ., seed) generates (V6:46)."""
+    return lib().orc_plgsy_entry(bump, seed, N, i, j)
+
+
+def plgsy_matrix(N: int, bump: float, seed: int) -> np.ndarray:
+    """The full symmetric matrix, LAPACK layout."""
+    A = np.empty((N, N), dtype=np.float64, order="F")
+    lib().orc_plgsy_matrix(A, N, N, bump, seed)
+    return A
 
 
 def plgsy_tiles(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
@@ -218,6 +234,78 @@ def residual_lower(L: np.ndarray, A: np.ndarray) -> float:
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+# --------------------------------------------------------------------------- V6 validation sequence
+def cholesky_lower_any(A: np.ndarray, B: int, nthreads: int = 0) -> tuple[np.ndarray, int]:
+    """cholesky_lower for any N: the matrix is extended by an identity block to a multiple of B
+    (which leaves the factor of the leading N x N part unchanged) and cropped afterwards."""
+    N = A.shape[0]
+    Np = (N + B - 1) // B * B
+    if Np == N:
+        return cholesky_lower(A, B, nthreads)
+    Ap = np.eye(Np, dtype=np.float64, order="F")
+    Ap[:N, :N] = A
+    L, info = cholesky_lower(Ap, B, nthreads)
+    return np.asfortranarray(L[:N, :N]), (info if info <= N else 0)
+
+
+def cham_plgsy_visible(N: int, NB: int, bump: float, seed: int, uplo: str = "L") -> np.ndarray:
+    """What CHAMELEON_dplgsy_Tile(bump, uplo, desc, seed) leaves in a zero-initialised N x N
+    descriptor with NB x NB tiles (V6:44-46): the tiles on the `uplo` side, and the diagonal
+    tiles in full (both triangles); the tiles on the other side are not touched."""
+    full = plgsy_matrix(N, bump, seed)
+    if uplo == "A":
+        return full
+    vis = np.tril(full) if uplo == "L" else np.triu(full)
+    for t in range(0, N, NB):
+        e = min(N, t + NB)
+        vis[t:e, t:e] = full[t:e, t:e]
+    return np.asfortranarray(vis)
+
+
+def cham_lange_inf(A: np.ndarray) -> float:
+    """CHAMELEON_dlange_Tile(ChamInfNorm, A) (V6:74, 85): max row sum of |a_ij|."""
+    return float(np.abs(A).sum(axis=1).max())
+
+
+def cham_lauum_lower(A: np.ndarray) -> np.ndarray:
+    """CHAMELEON_dlauum_Tile(ChamLower, A) (V6:80): tril(A) <- tril(L^T L), L = tril(A);
+    the strict upper triangle is not referenced (LAPACK dlauum)."""
+    L = np.tril(A)
+    out = np.array(A, order="F", copy=True)
+    il = np.tril_indices(A.shape[0])
+    out[il] = (L.T @ L)[il]
+    return out
+
+
+def v6_literal_validation(N: int, NB: int, seed: int = 42, nthreads: int = 0) -> dict:
+    """The validation sequence of v6_test.c exactly as written (V6:44-86), which is what produced
+    column 12 (rel_error) of the reference's bench.csv:
+
+        A     <- dplgsy(bump=N, ChamLower, seed)           lower tiles + full diagonal tiles
+        Aorig <- dlacpy(ChamUpperLower, A)
+        A     <- dpotrf(ChamLower, A)
+        normA <- dlange(Inf, Aorig)
+        R     <- 0; dlacpy(ChamLower, A -> R); dlauum(ChamLower, R)     R = tril(L^T L), not L L^T
+        Aorig <- Aorig - R   (dgeadd)                       over the whole matrix
+        rel   <- dlange(Inf, Aorig) / normA
+
+    It is not a residual of the factorisation: it is dominated by the strict
+    upper triangles of the diagonal tiles, which R does not have.  Restated because the recorded
+    values are the only numerical outputs of the reference and pin the generator and this
+    sequence to three digits."""
+    full = plgsy_matrix(N, float(N), seed)
+    vis = cham_plgsy_visible(N, NB, float(N), seed, "L")
+    L, info = cholesky_lower_any(full, NB, nthreads)
+    normA = cham_lange_inf(vis)
+    R = np.zeros((N, N), order="F")
+    il = np.tril_indices(N)
+    R[il] = L[il]
+    R = cham_lauum_lower(R)
+    D = vis - R
+    res = cham_lange_inf(D)
+    return {"info": info, "normA": normA, "residual": res, "rel": res / (normA if normA > 0 else 1.0)}
 
 
 # --------------------------------------------------------------------------- reference build

@@ -39,7 +39,7 @@ class OracleEngine:
                 t = self._np_tile(self.tiles_view(il, jl))
                 for jj in range(self.B):
                     for ii in range(self.B):
-                        t[ii, jj] = orc.plgsy_entry(bump, seed, I * self.B + ii, J * self.B + jj)
+                        t[ii, jj] = orc.plgsy_entry(bump, seed, self.N, I * self.B + ii, J * self.B + jj)
 
     def upload_tile(self, I, J, tile):
         self._np_tile(self.tiles_view(I // self.P, J // self.Q))[:, :] = tile

@@ -86,12 +86,12 @@ def test_reference_sweep_shapes_ragged_and_odd_tiles(cham, N, NB):
     zero-padded (v6_test.c:44 descriptor semantics); the library keeps a padded image inside."""
     ch = cham
     d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1)
-    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamUpperLower, d, 42)
     A = d.to_lapack()
     assert A.shape == (N, N) and np.array_equal(A, A.T) and np.diag(A).min() > N - 1
     from oracle import oracle as orc
 
-    assert A[N - 1, 3] == orc.plgsy_entry(float(N), 42, N - 1, 3)  # same generator, global indices
+    assert A[N - 1, 3] == orc.plgsy_entry(float(N), 42, N, N - 1, 3)  # same generator, global indices
     assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
     L = np.tril(d.to_lapack())
     Lref = np.linalg.cholesky(A)
