@@ -12,7 +12,12 @@
  *     functions (client_distrib.cpp:224-321) compiled from /root/reference by
  *     oracle/build_ref.sh into oracle/_ref/, and against the golden vectors in
  *     tests/golden/ that were produced by that build.
- *   - Tile arithmetic (POTRF/TRSM/SYRK/GEMM): PARITY UNPINNED.  The reference
+ *   - Driver-path generator (CHAMELEON_dplgsy_Tile, V6:46) and the V6:44-86
+ *     validation sequence: PINNED by the 35 rel_error values the reference
+ *     recorded in its bench.csv (tests/golden/reference_vm_rel_error.json),
+ *     all reproduced to every printed digit (see the generator's comment).
+ *     This bounds the error of the factor itself only at about 1e-3.
+ *   - Tile arithmetic (POTRF/TRSM/SYRK/GEMM) beyond that: PARITY UNPINNED.  The reference
  *     does no arithmetic of its own: it calls Chameleon (unpinned git HEAD) ->
  *     StarPU 1.4 -> OpenBLAS 0.3.26 / cuBLAS (Dockerfile.worker.v4:24,48,60),
  *     none of which is in /root/reference, and it holds no golden vectors or
