@@ -116,13 +116,16 @@ def v6_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr, dtype: int = ch
 
 
 CSV_HEADER = ["timestamp", "scheduler", "mapping", "ncpu", "ngpu", "N", "NB", "run_idx", "ms", "exit_code",
-              "gflops", "rel_error", "tflops", "pct_peak", "dtype"]
+              "gflops", "rel_error", "tflops", "pct_peak", "dtype", "residual_fro"]
 
 
 def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None, repeats: int = 8,
-          dtype: int = ch.ChamRealDouble, seed: int = 42, out=sys.stdout) -> list[dict]:
+          dtype: int = ch.ChamRealDouble, seed: int = 42, out=sys.stdout, as_written: bool = True) -> list[dict]:
     """BN:76-285: for every (N, NB): run 0 is the warm-up (the reference's StarPU calibration
-    run, BN:201), runs 1..repeats-1 are measured; one CSV row per run."""
+    run, BN:201), runs 1..repeats-1 are measured; one CSV row per run.  The first 12 columns keep
+    the reference's meaning: `rel_error` is the number v6_test.c:86 prints, from the reference's
+    own validation calls (v6_validation_as_written; -1 when as_written=False); `residual_fro`
+    is the true ||A - L L^T||_F / ||A||_F (last run of each (N, NB); -1 elsewhere)."""
     ch.CHAMELEON_Init(os.cpu_count() or 1, 1)
     peak = FP64_MFMA_PEAK_TFLOPS if dtype == ch.ChamRealDouble else FP32_MFMA_PEAK_TFLOPS
     rows = []
@@ -137,15 +140,20 @@ def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None,
     for N in Ns:
         for NB in NBs:
             d = ch.CHAMELEON_Desc_Create(None, dtype, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1)
+            dorig = ch.CHAMELEON_Desc_Create(None, dtype, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1) if as_written else None
             for r in range(repeats):
                 ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, seed)
+                if dorig is not None:
+                    ch.CHAMELEON_dlacpy_Tile(ch.ChamUpperLower, d, dorig)
                 info, secs = potrf_timed(d)
-                rel = ch.residual_plgsy(d, float(N), seed) if (info == 0 and r == repeats - 1) else -1.0
+                rel = v6_validation_as_written(d, dorig) if (info == 0 and dorig is not None) else -1.0
+                fro = ch.residual_plgsy(d, float(N), seed) if (info == 0 and r == repeats - 1) else -1.0
                 gf = N ** 3 / 3.0 / secs / 1e9
                 row = dict(timestamp=time.strftime("%Y-%m-%d %H:%M:%S"), scheduler="hip-streams", mapping="1gpu",
                            ncpu=0, ngpu=1, N=N, NB=NB, run_idx=r, ms=int(round(secs * 1e3)), exit_code=int(info != 0),
                            gflops=f"{gf:.6f}", rel_error=f"{rel:.6e}", tflops=f"{gf / 1e3:.4f}",
-                           pct_peak=f"{100 * gf / 1e3 / peak:.2f}", dtype="f64" if dtype == ch.ChamRealDouble else "f32")
+                           pct_peak=f"{100 * gf / 1e3 / peak:.2f}", dtype="f64" if dtype == ch.ChamRealDouble else "f32",
+                           residual_fro=f"{fro:.6e}")
                 rows.append(row)
                 if w:
                     w.writerow([row[k] for k in CSV_HEADER])
@@ -153,6 +161,8 @@ def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None,
                 print(f"   -> N={N} NB={NB} run={r} ms={secs * 1e3:.2f}  GF={gf:.2f}  err={rel:.2e}  exit={int(info != 0)}",
                       file=out)
             ch.CHAMELEON_Desc_Destroy(d)
+            if dorig is not None:
+                ch.CHAMELEON_Desc_Destroy(dorig)
     if f:
         f.close()
     return rows

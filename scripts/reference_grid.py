@@ -11,12 +11,17 @@ if os.path.exists(out):
 Ns = [1000, 5000, 8000, 12000, 16000]
 NBs = list(range(128, 513, 64))
 rows = driver.bench(Ns, NBs, csv_path=out, repeats=8, out=io.StringIO())
-print("N      " + " ".join(f"NB={nb:<6d}" for nb in NBs) + "  best (GFLOP/s, median of runs 1-7)   max rel_error")
+import json
+gold = {(c["N"], c["NB"]): c["rel_error"] for c in json.load(open(os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "reference_vm_rel_error.json")))["values"]}
+same = sum(1 for r in rows if "%.2e" % float(r["rel_error"]) == "%.2e" % float(gold[r["N"], r["NB"]]))
+print(f"rel_error column identical to the reference's bench.csv (to the printed %.2e digits): {same}/{len(rows)} rows")
+print("N      " + " ".join(f"NB={nb:<6d}" for nb in NBs) + "  best (GFLOP/s, median of runs 1-7)   max residual_fro")
 for N in Ns:
     meds, errs = [], []
     for nb in NBs:
         g = [float(r["gflops"]) for r in rows if r["N"] == N and r["NB"] == nb and r["run_idx"] > 0]
-        e = [float(r["rel_error"]) for r in rows if r["N"] == N and r["NB"] == nb and float(r["rel_error"]) >= 0]
+        e = [float(r["residual_fro"]) for r in rows if r["N"] == N and r["NB"] == nb and float(r["residual_fro"]) >= 0]
         meds.append(statistics.median(g) if g else float("nan"))
         errs += e
     best = max(range(len(NBs)), key=lambda i: meds[i])
