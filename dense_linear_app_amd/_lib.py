@@ -73,7 +73,8 @@ def lib() -> C.CDLL:
         "chol_wave_export_winv": ([vp, vp, vp], i),
         "chol_wave_import_winv": ([vp, vp, vp], i),
         "chol_wave_trsm": ([vp, i, vp, vp], i),
-        "chol_wave_update": ([vp, i, i, i, pp, C.POINTER(i), vp], i),
+        "chol_wave_update": ([vp, i, i, i, pp, C.POINTER(i), i, vp], i),
+        "chol_wave_update_diag": ([vp, i, i, pp, C.POINTER(i), vp], i),
         "chol_get_info": ([C.POINTER(i)], i),
         "chol_reset_info": ([], i),
     }

@@ -1071,14 +1071,9 @@ int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   return 0;
 }
 
-int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const *panel_base,
-                     const int *panel_first, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update before chol_init");
-  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update: NULL");
-  if (jlo <= k) jlo = k + 1;
-  if (jhi > d->nt) jhi = d->nt;
-  if (jlo >= jhi) return 0;
-  hipStream_t s = (hipStream_t)stream;
+static int wave_update_range(chol_desc_t *d, const void *const *panel_base, const int *panel_first, int lo,
+                             int hi, hipStream_t s) {
+  if (hi <= lo) return 0;
   PanelRef pan;
   memset(&pan, 0, sizeof pan);
   pan.P = d->p;
@@ -1086,7 +1081,6 @@ int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const 
     pan.base[r] = panel_base[r];
     pan.first[r] = panel_first[r];
   }
-  const int lo = d->ge[jhi], hi = d->ge[jlo];
   const LocalMat C = local_mat(d, d->mat);
   if (d->dtype == CHOL_REAL_DOUBLE)
     launch_trail_update<double>(s, C, d->d_list, lo, hi - lo, pan, true);
@@ -1094,6 +1088,40 @@ int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const 
     launch_trail_update<float>(s, C, d->d_list, lo, hi - lo, pan, true);
   HIPCHECK(hipGetLastError());
   return 0;
+}
+
+static inline bool owns_tile(const chol_desc *d, int I, int J) {
+  return I % d->p == d->prow && J % d->q == d->pcol;
+}
+
+int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const *panel_base,
+                     const int *panel_first, int skip_diag, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update before chol_init");
+  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update: NULL");
+  if (jlo <= k) jlo = k + 1;
+  if (jhi > d->nt) jhi = d->nt;
+  if (jlo >= jhi) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int lo = d->ge[jhi], hi = d->ge[jlo];
+  // the work list is sorted by column descending, rows ascending inside a column: the
+  // diagonal tile of column jlo, when this process owns it, is the first entry of the last segment
+  if (skip_diag && owns_tile(d, jlo, jlo)) {
+    const int dpos = d->ge[jlo + 1];
+    int rc = wave_update_range(d, panel_base, panel_first, lo, dpos, s);
+    if (rc) return rc;
+    return wave_update_range(d, panel_base, panel_first, dpos + 1, hi, s);
+  }
+  return wave_update_range(d, panel_base, panel_first, lo, hi, s);
+}
+
+int chol_wave_update_diag(chol_desc_t *d, int k, int j, const void *const *panel_base,
+                          const int *panel_first, void *stream) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update_diag before chol_init");
+  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update_diag: NULL");
+  if (j <= k || j >= d->nt) return fail(-3, "wave_update_diag: j out of range");
+  if (!owns_tile(d, j, j)) return fail(-3, "wave_update_diag: this process does not own tile (j,j)");
+  const int dpos = d->ge[j + 1];
+  return wave_update_range(d, panel_base, panel_first, dpos, dpos + 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

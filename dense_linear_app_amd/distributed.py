@@ -13,9 +13,17 @@ moves between GPUs per wave k is
      each rank then runs its local SYRK/GEMM updates from the replicated panel.
 
 The collectives are torch.distributed broadcasts (backend "nccl" = RCCL over xGMI on the
-GPUs, "gloo" in the CPU tests).  There is no all-reduce anywhere.  Panel k+1 is factored
-and broadcast on a side stream while the bulk of update k runs (one wave of lookahead),
-and its receive buffers are double-buffered by wave parity.
+GPUs, "gloo" in the CPU tests).  There is no all-reduce anywhere.
+
+Schedule (three streams per rank, receive buffers double-buffered by wave parity):
+
+  main   U1(k) = update of columns k+1, k+2 by panel k;  U2(k) = the columns beyond
+  side   TRSM(k+1), then the broadcasts of panel k+1 -- first its head tile L(k+2,k+1) alone,
+         then the parts -- while U2(k) runs (one wave of lookahead)
+  early  as soon as the head tile L(k+1,k) is in: the owner of (k+1,k+1) applies that one SYRK,
+         factors the tile and broadcasts it down its process column -- while the rest of panel k
+         is still on the wire.  POTRF and the L(k,k) broadcast are thereby off the per-wave
+         critical path, which is  panel broadcast -> U1 -> TRSM -> next panel broadcast.
 
 The wave logic is written against a small `engine` interface so that the CPU tests can
 drive it with world_size 2 on gloo; the product engine is `HipEngine` (libcholmi.so,
@@ -144,11 +152,18 @@ class HipEngine:
     def trsm(self, k: int, lkk, s) -> None:
         self._check("chol_wave_trsm", self._lib.chol_wave_trsm(self.desc.handle, k, lkk.data_ptr(), self._sp(s)))
 
-    def update(self, k: int, jlo: int, jhi: int, bases: Sequence, firsts: Sequence[int], s) -> None:
+    def update(self, k: int, jlo: int, jhi: int, bases: Sequence, firsts: Sequence[int], s,
+               skip_diag: bool = False) -> None:
         pb = (C.c_void_p * self.P)(*[b.data_ptr() for b in bases])
         pf = (C.c_int * self.P)(*firsts)
         self._check("chol_wave_update",
-                    self._lib.chol_wave_update(self.desc.handle, k, jlo, jhi, pb, pf, self._sp(s)))
+                    self._lib.chol_wave_update(self.desc.handle, k, jlo, jhi, pb, pf, int(skip_diag), self._sp(s)))
+
+    def update_diag(self, k: int, j: int, bases: Sequence, firsts: Sequence[int], s) -> None:
+        pb = (C.c_void_p * self.P)(*[b.data_ptr() for b in bases])
+        pf = (C.c_int * self.P)(*firsts)
+        self._check("chol_wave_update_diag",
+                    self._lib.chol_wave_update_diag(self.desc.handle, k, j, pb, pf, self._sp(s)))
 
     def reset_info(self) -> None:
         self._check("chol_reset_info", self._lib.chol_reset_info())
@@ -171,19 +186,11 @@ class BlockCyclicCholesky:
     of the panel instead of a ring carrying all of it.  Same result, same panel addressing.
     """
 
-    def __init__(self, engine, dist, lookahead: bool = True, panel_mode: Optional[str] = None,
-                 panel_first: Optional[bool] = None):
+    def __init__(self, engine, dist, lookahead: bool = True, panel_mode: Optional[str] = None):
         import os
 
         self.e, self.dist, self.lookahead = engine, dist, lookahead
         self.panel_mode = panel_mode or os.environ.get("CHOLMI_PANEL_MODE", "bcast")
-        # Optional: on the ranks that factor / solve panel k+1, hold back the bulk of update k until
-        # their panel kernels are done.  Off by default: the update kernel already yields its CUs
-        # to the panel chain's workgroups (DESIGN.md section 3, cooperative CU hand-over), which keeps
-        # the rest of the GPU busy; this switch idles the whole GPU instead (CHOLMI_PANEL_FIRST=1).
-        env = os.environ.get("CHOLMI_PANEL_FIRST")
-        self.panel_first = panel_first if panel_first is not None else (env == "1")
-        self._panel_done = None
         assert self.panel_mode in ("bcast", "allgather")
         e = engine
         self.world = dist.get_world_size()
@@ -197,6 +204,8 @@ class BlockCyclicCholesky:
         # L(k,k) and, right behind it, the inverses of its 128-blocks: one broadcast per wave
         self.nwinv = e.winv_elems() if hasattr(e, "winv_elems") else 0
         self.lkk_buf = [e.empty_tiles(2)[:e.bsiz + self.nwinv] for _ in range(2)]
+        self.head_buf = [e.empty_tiles(1) for _ in range(2)]  # L(k+1,k), sent ahead of the parts
+        self._lkk = [None, None]
         if self.panel_mode == "bcast":
             # receive buffers: [parity][process row]
             self.pbuf = [[e.empty_tiles(maxpart) for _ in range(e.P)] for _ in range(2)]
@@ -232,8 +241,8 @@ class BlockCyclicCholesky:
                 dist.all_gather([out[r * 8:(r + 1) * 8] for r in range(self.world)], t)
         e.synchronize()
 
-    # -- L(k,k): POTRF on its owner, broadcast down the process column, TRSM of the local panel tiles
-    def _diag_and_trsm(self, k: int, s) -> None:
+    # -- L(k,k): POTRF on its owner, broadcast (with its block inverses) down the process column
+    def _diag(self, k: int, s) -> None:
         e, dist = self.e, self.dist
         P, Q = e.P, e.Q
         pr, pc = k % P, k % Q
@@ -241,27 +250,43 @@ class BlockCyclicCholesky:
         if e.pcol != pc:
             return
         buf = self.lkk_buf[par]
+        last = k + 1 >= e.nt
         if e.prow == pr:
             lkk = e.tiles_view(k // P, k // Q)
             e.potrf(k, lkk, s)
-            if P > 1 and k + 1 < e.nt:
+            if P > 1 and not last:
                 # ship the factored tile together with the inverses of its diagonal blocks
                 buf[:e.bsiz].copy_(lkk)
                 if self.nwinv:
                     e.export_winv(buf[e.bsiz:], s)
         else:
             lkk = buf[:e.bsiz]
-        if P > 1 and k + 1 < e.nt:
+        if P > 1 and not last:
             dist.broadcast(buf, src=pr * Q + pc, group=self.col_groups[pc])
             if e.prow != pr:
                 if self.nwinv:
                     e.import_winv(buf[e.bsiz:], s)
                 else:
                     e.invert_diag(lkk, s)
-        if k + 1 < e.nt:
-            e.trsm(k, lkk, s)
-        if self.panel_first:
-            self._panel_done = e.record(s)  # this rank's share of the panel computation is enqueued
+        self._lkk[par] = lkk
+
+    # -- TRSM of the local tiles of panel k, then its head tile L(k+1,k) ahead of everything else.
+    # Returns (tile holding L(k+1,k) on this rank, event recorded once it is there).
+    def _trsm_and_head(self, k: int, s, send_head: bool):
+        e, dist = self.e, self.dist
+        P, Q = e.P, e.Q
+        if e.pcol == k % Q:
+            e.trsm(k, self._lkk[k & 1], s)
+        if not send_head or k + 1 >= e.nt:
+            return None, None
+        src = ((k + 1) % P) * Q + k % Q
+        if e.rank == src:
+            head = e.tiles_view((k + 1) // P, k // Q)
+        else:
+            head = self.head_buf[k & 1]
+        if self.world > 1:
+            dist.broadcast(head, src=src)
+        return head, e.record(s)
 
     def _part(self, k: int, p2: int):
         """(first local row, tile count) of the part of panel k owned by process row p2."""
@@ -274,7 +299,6 @@ class BlockCyclicCholesky:
         e, dist = self.e, self.dist
         P, Q = e.P, e.Q
         pc, par = k % Q, k & 1
-        self._diag_and_trsm(k, s)
         bases, firsts = [], []
         for p2 in range(P):
             il0, cnt = self._part(k, p2)
@@ -294,7 +318,6 @@ class BlockCyclicCholesky:
         e, dist = self.e, self.dist
         P, Q, bs = e.P, e.Q, e.bsiz
         pc, par = k % Q, k & 1
-        self._diag_and_trsm(k, s)
         parts = [self._part(k, p2) for p2 in range(P)]
         chunk = max((cnt + Q - 1) // Q for _, cnt in parts)
         gbuf, cbuf, tail = self.gbuf[par], self.cbuf[par], self.tail[par]
@@ -333,36 +356,64 @@ class BlockCyclicCholesky:
             out.copy_(mine)
         return bases, firsts
 
-    def _panel(self, k: int, s):
-        return self._panel_bcast(k, s) if self.panel_mode == "bcast" else self._panel_allgather(k, s)
+    def _panel(self, k: int, s, send_head: bool = True):
+        """TRSM(k) and the replication of panel k, on stream s.  -> (bases, firsts, head, head event)"""
+        head, ev_head = self._trsm_and_head(k, s, send_head)
+        bases, firsts = self._panel_bcast(k, s) if self.panel_mode == "bcast" else self._panel_allgather(k, s)
+        return bases, firsts, head, ev_head
 
     def factorize(self) -> int:
         """In place on the engine's tiles.  Returns LAPACK info (max over ranks)."""
         e = self.e
+        nt, P, Q = e.nt, e.P, e.Q
         main = e.main_stream()
-        side = e.new_stream() if self.lookahead else main
         e.reset_info()
-        e.wait(side, main)
-        with e.stream_ctx(side):
-            panel = self._panel(0, side)
-        for k in range(e.nt - 1):
-            e.wait(main, side)  # panel k complete (and received) before it is used
-            bases, firsts = panel
-            if self.lookahead:
-                # column k+1 first, so that panel k+1 can start under the rest of update k
-                e.update(k, k + 1, k + 2, bases, firsts, main)
-                e.wait(side, main)
-                self._panel_done = None
+        if not self.lookahead:
+            # the plain wave order on one stream (C2:506-565)
+            with e.stream_ctx(main):
+                for k in range(nt):
+                    self._diag(k, main)
+                    if k + 1 < nt:
+                        bases, firsts, _, _ = self._panel(k, main, send_head=False)
+                        e.update(k, k + 1, nt, bases, firsts, main)
+        else:
+            side, early = self._streams()
+            e.wait(side, main)
+            e.wait(early, main)
+            with e.stream_ctx(early):
+                self._diag(0, early)
+            e.wait(side, early)
+            panel = None
+            if nt > 1:
                 with e.stream_ctx(side):
-                    panel = self._panel(k + 1, side)
-                if self._panel_done is not None:
-                    e.wait_event(main, self._panel_done)
-                e.update(k, k + 2, e.nt, bases, firsts, main)
-            else:
-                e.update(k, k + 1, e.nt, bases, firsts, main)
-                with e.stream_ctx(main):
-                    panel = self._panel(k + 1, main)
-        e.wait(main, side)
+                    panel = self._panel(0, side)
+            ev_u1 = None
+            for k in range(nt - 1):
+                bases, firsts, head, ev_head = panel
+                # early: the diagonal tile of the next wave, as soon as the head tile L(k+1,k) is in
+                e.wait_event(early, ev_head)
+                if ev_u1 is not None:
+                    e.wait_event(early, ev_u1)  # (k+1,k+1) carries every update up to wave k-1
+                with e.stream_ctx(early):
+                    if owner_of(k + 1, k + 1, P, Q) == e.rank:
+                        hb = [head] * P
+                        hf = [0] * P
+                        hf[(k + 1) % P] = (k + 1) // P
+                        e.update_diag(k, k + 1, hb, hf, early)
+                    self._diag(k + 1, early)
+                ev_diag = e.record(early)
+                # main: panel k complete (and received); columns k+1 and k+2 first
+                e.wait(main, side)
+                e.update(k, k + 1, k + 3, bases, firsts, main, skip_diag=True)
+                ev_u1 = e.record(main)
+                if k + 2 < nt:
+                    e.wait_event(side, ev_u1)
+                    e.wait_event(side, ev_diag)
+                    with e.stream_ctx(side):
+                        panel = self._panel(k + 1, side)
+                e.update(k, k + 3, nt, bases, firsts, main)
+            e.wait(main, side)
+            e.wait(main, early)
         e.synchronize()
         info = e.info()
         if self.world > 1:
@@ -375,6 +426,11 @@ class BlockCyclicCholesky:
             v = int(t.item())
             info = 0 if v == 0 else (1 << 40) - v
         return info
+
+    def _streams(self):
+        if getattr(self, "_side", None) is None:
+            self._side, self._early = self.e.new_stream(), self.e.new_stream()
+        return self._side, self._early
 
 
 def run(N: int, B: int, dist, dtype: str = "f64", seed: int = 42, bump: Optional[float] = None,

@@ -203,9 +203,16 @@ int chol_wave_import_winv(chol_desc_t *desc, const void *src, void *stream);
 /* TRSM of this process's tiles (i,k), i > k, against `lkk`. */
 int chol_wave_trsm(chol_desc_t *desc, int k, const void *lkk, void *stream);
 /* Trailing update of this process's tiles (i,j), j in [jlo, jhi), i >= j, i > k,
- * with panel tile i read from panel_base[i % p] + (i/p - panel_first[i % p])*bsiz. */
+ * with panel tile i read from panel_base[i % p] + (i/p - panel_first[i % p])*bsiz.
+ * skip_diag != 0: leave out tile (jlo, jlo) -- its owner has already updated (and factored)
+ * it ahead of the rest with chol_wave_update_diag. */
 int chol_wave_update(chol_desc_t *desc, int k, int jlo, int jhi, const void *const *panel_base,
-                     const int *panel_first, void *stream);
+                     const int *panel_first, int skip_diag, void *stream);
+/* The one SYRK  C(j,j) -= L(j,k) L(j,k)^T  on the owner of (j,j), as soon as L(j,k) has
+ * arrived (panel_base[j % p] / panel_first[j % p] address it): lets POTRF(j) start while
+ * the rest of panel k is still on the wire. */
+int chol_wave_update_diag(chol_desc_t *desc, int k, int j, const void *const *panel_base,
+                          const int *panel_first, void *stream);
 int chol_get_info(int *info); /* device-side POTRF status word of the current factorisation */
 int chol_reset_info(void);
 

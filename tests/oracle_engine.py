@@ -88,13 +88,19 @@ class OracleEngine:
             t = self._np_tile(self.tiles_view(il, k // self.Q))
             t[:, :] = orc.dtrsm(L, t)
 
-    def update(self, k, jlo, jhi, bases, firsts, s):
+    def update_diag(self, k, j, bases, firsts, s):
+        assert j % self.Q == self.pcol and j % self.P == self.prow and k < j < self.nt
+        Aj = self._np_tile(bases[j % self.P], j // self.P - firsts[j % self.P])
+        Cm = self._np_tile(self.tiles_view(j // self.P, j // self.Q))
+        Cm[:, :] = orc.dsyrk(Aj, Cm)
+
+    def update(self, k, jlo, jhi, bases, firsts, s, skip_diag=False):
         jlo = max(jlo, k + 1)
         for j in range(jlo, min(jhi, self.nt)):
             if j % self.Q != self.pcol:
                 continue
             for i in range(j, self.nt):
-                if i % self.P != self.prow:
+                if i % self.P != self.prow or (skip_diag and i == j == jlo):
                     continue
                 Ai = self._np_tile(bases[i % self.P], i // self.P - firsts[i % self.P])
                 Aj = self._np_tile(bases[j % self.P], j // self.P - firsts[j % self.P])
