@@ -30,10 +30,12 @@ struct chol_desc {
   void *mat;         // storage as seen by the caller (host or device)
   bool on_device;    // mat is device memory
   bool owns;         // library allocated mat
-  // static work list of the trailing updates: local lower tiles sorted by column
-  // descending; entries with column >= j occupy [0, ge[j])
+  // static work list of the trailing updates: the local strictly-lower tiles sorted by column
+  // descending (rows ascending inside a column), entries with column >= j in [0, ge[j]); then,
+  // from n_off on, the local diagonal tiles sorted by column descending, [n_off, n_off + gd[j])
   int2 *d_list = nullptr;
-  std::vector<int> ge;
+  std::vector<int> ge, gd;
+  int n_off = 0;
 };
 
 namespace {
@@ -172,6 +174,19 @@ int read_info(int *info) {
   return 0;
 }
 
+// the work-list segments of the tiles in columns [jlo, jhi)
+struct ColRange {
+  int off, na, offb, nb;
+};
+static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
+  ColRange r;
+  r.off = d->ge[jhi];
+  r.na = d->ge[jlo] - d->ge[jhi];
+  r.offb = d->n_off + d->gd[jhi];
+  r.nb = d->gd[jlo] - d->gd[jhi];
+  return r;
+}
+
 // ---- whole-matrix right-looking tiled Cholesky on one GPU --------------------
 template <typename T>
 int potrf_full_device(chol_desc *d, void *base) {
@@ -213,7 +228,8 @@ int potrf_full_device(chol_desc *d, void *base) {
       pan.P = 1;
       pan.base[0] = M + (long)k * nt * bsiz;
       pan.first[0] = 0;
-      const int u1_lo = d->ge[k + 2 <= nt ? k + 2 : nt], u1_hi = d->ge[k + 1];
+      const ColRange r1 = col_range(d, k + 1, k + 2 <= nt ? k + 2 : nt), r2 = col_range(d, k + 2 <= nt ? k + 2 : nt, nt);
+      const int u1_hi = r1.na + r1.nb + r2.na + r2.nb;  // tiles of this wave's update
       hipEvent_t p0 = nullptr, p1 = nullptr, p2 = nullptr;
       if (g.profiling) {
         p0 = g.events[2 * nt + 8 + 3 * k];
@@ -227,12 +243,12 @@ int potrf_full_device(chol_desc *d, void *base) {
       const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
       const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
       const bool yield = (double)u1_hi * t_tile < 6.0 * t_panel;
-      launch_trail_update<T>(g.s_main, C, d->d_list, u1_lo, u1_hi - u1_lo, pan, yield);
+      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
       if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
       HIPCHECK(hipEventRecord(ev_u1, g.s_main));
       HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
-      if (u1_lo > 0) {
-        launch_trail_update<T>(g.s_main, C, d->d_list, 0, u1_lo, pan, yield);
+      if (r2.na + r2.nb > 0) {
+        launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
         ++upd_launches;
       }
       if (g.profiling) HIPCHECK(hipEventRecord(p2, g.s_main));
@@ -270,19 +286,25 @@ int potrf_full_device(chol_desc *d, void *base) {
 
 int build_worklist(chol_desc *d) {
   if (d->mt != d->nt) return 0;  // only square tile grids are factored
-  std::vector<int2> list;
+  std::vector<int2> off, dg;
   d->ge.assign(d->nt + 2, 0);
+  d->gd.assign(d->nt + 2, 0);
+  // diagnostic only (single-process descriptors): keep the diagonal tiles where the column order
+  // puts them, to measure what moving them to the end of a launch buys
+  const char *ord = getenv("CHOLMI_LIST_ORDER");
+  const bool interleaved = ord && !strcmp(ord, "interleaved") && d->p * d->q == 1;
   for (int J = d->nt - 1; J >= 0; --J) {
     if (J % d->q == d->pcol)
       for (int I = J; I < d->mt; ++I)
-        if (I % d->p == d->prow) list.push_back(make_int2(I, J));
-    d->ge[J] = (int)list.size();
+        if (I % d->p == d->prow) ((I == J && !interleaved) ? dg : off).push_back(make_int2(I, J));
+    d->ge[J] = (int)off.size();
+    d->gd[J] = (int)dg.size();
   }
-  d->ge[d->nt] = 0;
-  d->ge[d->nt + 1] = 0;
-  if (!list.empty()) {
-    HIPCHECK(hipMalloc(&d->d_list, list.size() * sizeof(int2)));
-    HIPCHECK(hipMemcpy(d->d_list, list.data(), list.size() * sizeof(int2), hipMemcpyHostToDevice));
+  d->n_off = (int)off.size();
+  off.insert(off.end(), dg.begin(), dg.end());
+  if (!off.empty()) {
+    HIPCHECK(hipMalloc(&d->d_list, off.size() * sizeof(int2)));
+    HIPCHECK(hipMemcpy(d->d_list, off.data(), off.size() * sizeof(int2), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -921,15 +943,15 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   pan.P = 1;
   pan.base[0] = (char *)d->mat + (size_t)k * d->nt * d->bsizi * d->esize;
   const LocalMat C = local_mat(d, d->mat);
-  const int ntiles = d->ge[k + 1];
+  const ColRange rr = col_range(d, k + 1, d->nt);
   cholmi::g_ablate = ablate;
   float best = 1e30f;
   for (int r = 0; r <= reps; ++r) {
     HIPCHECK(hipEventRecord(g.events[0], g.s_main));
     if (d->dtype == CHOL_REAL_DOUBLE)
-      launch_trail_update<double>(g.s_main, C, d->d_list, 0, ntiles, pan);
+      launch_trail_update<double>(g.s_main, C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
     else
-      launch_trail_update<float>(g.s_main, C, d->d_list, 0, ntiles, pan);
+      launch_trail_update<float>(g.s_main, C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
     HIPCHECK(hipEventRecord(g.events[1], g.s_main));
     HIPCHECK(hipStreamSynchronize(g.s_main));
     float t = 0;
@@ -1071,21 +1093,21 @@ int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   return 0;
 }
 
-static int wave_update_range(chol_desc_t *d, const void *const *panel_base, const int *panel_first, int lo,
-                             int hi, hipStream_t s) {
-  if (hi <= lo) return 0;
+static int wave_update_range(chol_desc_t *d, const void *const *panel_base, const int *panel_first,
+                             const ColRange &r, hipStream_t s) {
+  if (r.na + r.nb <= 0) return 0;
   PanelRef pan;
   memset(&pan, 0, sizeof pan);
   pan.P = d->p;
-  for (int r = 0; r < d->p; ++r) {
-    pan.base[r] = panel_base[r];
-    pan.first[r] = panel_first[r];
+  for (int q = 0; q < d->p; ++q) {
+    pan.base[q] = panel_base[q];
+    pan.first[q] = panel_first[q];
   }
   const LocalMat C = local_mat(d, d->mat);
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_trail_update<double>(s, C, d->d_list, lo, hi - lo, pan, true);
+    launch_trail_update<double>(s, C, d->d_list, r.off, r.na, r.offb, r.nb, pan, true);
   else
-    launch_trail_update<float>(s, C, d->d_list, lo, hi - lo, pan, true);
+    launch_trail_update<float>(s, C, d->d_list, r.off, r.na, r.offb, r.nb, pan, true);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -1101,17 +1123,11 @@ int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const 
   if (jlo <= k) jlo = k + 1;
   if (jhi > d->nt) jhi = d->nt;
   if (jlo >= jhi) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  const int lo = d->ge[jhi], hi = d->ge[jlo];
-  // the work list is sorted by column descending, rows ascending inside a column: the
-  // diagonal tile of column jlo, when this process owns it, is the first entry of the last segment
-  if (skip_diag && owns_tile(d, jlo, jlo)) {
-    const int dpos = d->ge[jlo + 1];
-    int rc = wave_update_range(d, panel_base, panel_first, lo, dpos, s);
-    if (rc) return rc;
-    return wave_update_range(d, panel_base, panel_first, dpos + 1, hi, s);
-  }
-  return wave_update_range(d, panel_base, panel_first, lo, hi, s);
+  ColRange r = col_range(d, jlo, jhi);
+  // diagonal tiles are listed by column descending: that of column jlo, when this process owns
+  // it, is the last one of the segment
+  if (skip_diag && owns_tile(d, jlo, jlo)) --r.nb;
+  return wave_update_range(d, panel_base, panel_first, r, (hipStream_t)stream);
 }
 
 int chol_wave_update_diag(chol_desc_t *d, int k, int j, const void *const *panel_base,
@@ -1120,8 +1136,12 @@ int chol_wave_update_diag(chol_desc_t *d, int k, int j, const void *const *panel
   if (!d || !panel_base || !panel_first) return fail(-1, "wave_update_diag: NULL");
   if (j <= k || j >= d->nt) return fail(-3, "wave_update_diag: j out of range");
   if (!owns_tile(d, j, j)) return fail(-3, "wave_update_diag: this process does not own tile (j,j)");
-  const int dpos = d->ge[j + 1];
-  return wave_update_range(d, panel_base, panel_first, dpos, dpos + 1, (hipStream_t)stream);
+  ColRange r;
+  r.off = 0;
+  r.na = 0;
+  r.offb = d->n_off + d->gd[j + 1];
+  r.nb = 1;
+  return wave_update_range(d, panel_base, panel_first, r, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -37,11 +37,13 @@ extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;
 
 // ---- launchers (kernels.hip) ---------------------------------------------
-// C(i,j) -= L(i,k) L(j,k)^T for the `ntiles` (i,j) pairs in d_list[off .. off+ntiles);
+// C(i,j) -= L(i,k) L(j,k)^T for the (i,j) pairs in d_list[off .. off+na) followed by
+// d_list[offb .. offb+nb) (off-diagonal tiles first, the diagonal tiles -- whose blocks above the
+// diagonal exit at once -- last, so that they do not split the 64-block cohorts of an XCD);
 // yield: the update's waves give their CU to guest workgroups of the panel chain (kernels.hip)
 template <typename T>
-void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int ntiles,
-                         const PanelRef &pan, bool yield = false);
+void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
+                         int nb, const PanelRef &pan, bool yield = false);
 
 // In-tile blocked POTRF of one mb x mb tile (device pointer, ld = mb).  Writes the
 // inverses of the MACRO x MACRO diagonal blocks of L to winv (mb/MACRO blocks of

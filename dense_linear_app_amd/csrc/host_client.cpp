@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include "../../include/cholmi.h"
 
@@ -14,34 +15,56 @@ extern "C" {
 
 // C2:224-252: fill one triangle column by column from mt19937_64(seed) through
 // uniform_real_distribution(-0.5, 0.5), mirror it, then add `bump` to the diagonal.
+// libstdc++ maps one 64-bit draw r to  u = (double)((long double)r / 2^64), clamps u == 1 to
+// nextafter(1, 0), and returns u * (b - a) + a; r -> double rounds to nearest-even exactly like
+// the long-double quotient does, so the same bits come out of plain double arithmetic (the
+// golden SHA-256 of the reference's own output pin this: tests/test_host_api.py).
 void chol_make_spd_like_chameleon(double *A, int N, int LDA, double bump, char uplo,
                                   unsigned long long seed) {
   std::mt19937_64 gen(seed);
-  std::uniform_real_distribution<double> dist(-0.5, 0.5);
   const size_t ld = (size_t)LDA;
   const bool lower = (uplo == 'L' || uplo == 'l');
   for (int j = 0; j < N; ++j) {
     const int i0 = lower ? j : 0, i1 = lower ? N : j + 1;
-    for (int i = i0; i < i1; ++i) A[i + j * ld] = dist(gen);
+    double *col = A + j * ld;
+    for (int i = i0; i < i1; ++i) {
+      double u = (double)gen() * 0x1p-64;
+      if (u >= 1.0) u = std::nextafter(1.0, 0.0);
+      col[i] = u * 1.0 + -0.5;
+    }
   }
-  for (int j = 0; j < N; ++j) {
-    if (lower)
-      for (int i = 0; i < j; ++i) A[i + j * ld] = A[j + i * ld];
-    else
-      for (int i = j + 1; i < N; ++i) A[i + j * ld] = A[j + i * ld];
-  }
+  // mirror, in cache-sized blocks (the values do not depend on the order)
+  constexpr int TB = 64;
+  for (int jb = 0; jb < N; jb += TB)
+    for (int ib = 0; ib <= jb; ib += TB) {
+      const int je = jb + TB < N ? jb + TB : N, ie = ib + TB < N ? ib + TB : N;
+      for (int j = jb; j < je; ++j)
+        for (int i = ib; i < ie && i < j; ++i) {
+          // (i, j) is strictly upper: i < j
+          if (lower)
+            A[i + j * ld] = A[j + i * ld];
+          else
+            A[j + i * ld] = A[i + j * ld];
+        }
+    }
   for (int i = 0; i < N; ++i) A[i + i * ld] += bump;
 }
 
 // C2:255-264: raise each diagonal entry to (sum of |off-diagonal| of its row) + eps
-// when it is smaller; rows are summed in column order j = 0..N-1.
+// when it is smaller; rows are summed in column order j = 0..N-1.  Swept column by column
+// (unit stride) with one running sum per row: every row still adds its terms in the order
+// j = 0..N-1, so the sums are bit-identical to the reference's row-by-row loop, and a
+// row's sum never involves a diagonal entry, so the order of the fix-ups does not matter.
 void chol_enforce_strict_diag_dominance(double *A, int N, int LDA, double eps) {
   const size_t ld = (size_t)LDA;
+  std::vector<double> s((size_t)N, 0.0);
+  for (int j = 0; j < N; ++j) {
+    const double *col = A + j * ld;
+    for (int i = 0; i < j; ++i) s[i] += std::abs(col[i]);
+    for (int i = j + 1; i < N; ++i) s[i] += std::abs(col[i]);
+  }
   for (int i = 0; i < N; ++i) {
-    double s = 0.0;
-    for (int j = 0; j < N; ++j)
-      if (j != i) s += std::abs(A[i + j * ld]);
-    const double need = s + eps - A[i + i * ld];
+    const double need = s[i] + eps - A[i + i * ld];
     if (need > 0.0) A[i + i * ld] += need;
   }
 }

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-task cost of the worker path (ArmoniK-style client -> DagCholeskyWorker -> C ABI) on the GPU."""
+import cProfile, io, os, pstats, sys, time
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
+from dense_linear_app_amd import chameleon as ch, client
+
+ch.CHAMELEON_Init(1, 1)
+N, B = int(sys.argv[1]), int(sys.argv[2])
+for dev in (False, True):
+    client.run_cholesky_dag(min(N, 4 * B), B, device_results=dev)  # warm
+    t = time.perf_counter()
+    r = client.run_cholesky_dag(N, B, device_results=dev)
+    dt = time.perf_counter() - t
+    n = sum(r.task_counts.values())
+    print(f"device_results={dev}: N={N} B={B} {n} tasks, DAG {r.seconds:.3f} s = {r.seconds / n * 1e3:.3f} ms/task "
+          f"({N**3 / 3 / r.seconds / 1e12:.3f} TFLOP/s), whole call {dt:.3f} s", flush=True)
+pr = cProfile.Profile()
+pr.enable()
+client.run_cholesky_dag(N, B, device_results=True)
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
+print(s.getvalue()[:5000])
