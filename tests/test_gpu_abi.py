@@ -2,6 +2,7 @@
 negative statuses for bad arguments, CHOL_ERR_NOT_SUPPORTED for valid-but-uncovered
 Chameleon usage (never a wrong answer), randomised shapes/scalars against the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -156,3 +157,27 @@ def test_potrf_trsm_random_spd(cham, orc, B, seed):
     X0 = X.copy()
     assert ch.CHAMELEON_dtrsm_Tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, mk(L), mk(X)) == 0
     assert np.abs(X @ Lref.T - X0).max() <= 256 * max(B, 8) * np.finfo(float).eps * max(1.0, np.abs(X).max()) * np.abs(Lref).max()
+
+
+def test_plain_c_driver_reproduces_reference_outputs():
+    """examples/v6_driver (C99, links libcholmi.so only): same arguments and output lines as the
+    reference's v6_test.c; its validation line equals the value the reference recorded."""
+    import json
+    import re
+    import subprocess
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = os.path.join(root, "examples", "v6_driver")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "all"])
+    with open(os.path.join(root, "tests", "golden", "reference_vm_rel_error.json")) as f:
+        gold = {(c["N"], c["NB"]): c["rel_error"] for c in json.load(f)["values"]}
+    for N, NB in ((1000, 128), (5000, 320), (8000, 512)):
+        args = [1, 1, N, NB, NB, NB, NB * NB, N, N, 0, 0, N, N, 1, 1, 42]
+        r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert re.search(r"Performance: [0-9.]+ Gflop/s", r.stdout)
+        m = re.search(r"\|\|A - LL\^T\|\|_inf / \|\|A\|\|_inf = ([0-9.e+-]+)", r.stdout)
+        assert m and m.group(1) == "%.2e" % float(gold[N, NB]), r.stdout
+        m = re.search(r"\|\|A - L L\^T\|\|_F / \|\|A\|\|_F = ([0-9.e+-]+)", r.stdout)
+        assert m and float(m.group(1)) <= 1e-13, r.stdout

@@ -200,3 +200,21 @@ def test_ragged_matrix_fails_like_the_reference():
     POTRF reports info > 0 and the client's wait fails."""
     with pytest.raises(ak.ResultNotAvailable, match="dpotrf info=3"):
         client.run_cholesky_dag(10, 4, worker=DagCholeskyWorker(backend=OracleTileBackend()))
+
+
+def test_c_driver_builds_as_c99_and_fails_loudly_without_a_gpu():
+    """examples/v6_driver.c: the reference driver's call sequence on include/cholmi.h, compiled by
+    a C compiler with -std=c99 -pedantic (the ABI is C: no C++, no torch types)."""
+    import subprocess
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "all"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "examples", "v6_driver")
+    r = subprocess.run([exe, "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        args = "1 1 256 128 128 128 16384 256 256 0 0 256 256 1 1 42".split()
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
