@@ -195,13 +195,14 @@ int potrf_full_device(chol_desc *d, void *base) {
   T *M = reinterpret_cast<T *>(base);
   T *winv = reinterpret_cast<T *>(g.winv);
   const int nbm_ev = mb / MACRO;
-  int rc = ensure_events(2 * (size_t)nt + 8 + nbm_ev + 4 * (size_t)nt);
+  int rc = ensure_events(2 * (size_t)nt + 8 + nbm_ev + 5 * (size_t)nt);
   if (rc) return rc;
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
   hipEvent_t ev_start = g.events[2 * nt], ev_stop = g.events[2 * nt + 1], ev_join = g.events[2 * nt + 2];
   hipEvent_t ev_wave = g.events[2 * nt + 3], ev_trsm = g.events[2 * nt + 4];
   hipEvent_t *ev_steps = &g.events[2 * nt + 8 + 4 * nt];
+  hipEvent_t *ev_u1r = &g.events[2 * nt + 8 + 4 * nt + nbm_ev];  // rest of column k+1 updated (one per wave)
   HIPCHECK(hipEventRecord(ev_start, g.s_main));
   HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_start, 0));
   const LocalMat C = local_mat(d, base);
@@ -209,11 +210,13 @@ int potrf_full_device(chol_desc *d, void *base) {
   int upd_launches = 0;
   for (int k = 0; k < nt; ++k) {
     hipEvent_t ev_panel = g.events[2 * k], ev_u1 = g.events[2 * k + 1];
-    HIPCHECK(hipEventRecord(ev_wave, g.s_panel));  // s_panel has waited for U1(k-1): the TRSM stream follows
+    HIPCHECK(hipEventRecord(ev_wave, g.s_panel));  // s_panel has waited for the SYRK on (k,k) by panel k-1
     // panel stream: POTRF(k,k) then TRSM(i,k), i > k  (C2:510-535)
     T *lkk = M + ((long)k + (long)k * nt) * bsiz;
-    // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream
+    // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream, which
+    // also needs the rest of column k updated by panel k-1
     HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev_wave, 0));
+    if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev_u1r[k - 1], 0));
     launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv, g.d_info, k * mb, lkk + bsiz, bsiz,
                               nt - 1 - k);
     HIPCHECK(hipEventRecord(ev_trsm, g.s_trsm));
@@ -243,10 +246,15 @@ int potrf_full_device(chol_desc *d, void *base) {
       const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
       const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
       const bool yield = (double)u1_hi * t_tile < 6.0 * t_panel;
-      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
-      if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
+      // the diagonal tile (k+1,k+1) alone first: POTRF(k+1) needs nothing else
+      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
       HIPCHECK(hipEventRecord(ev_u1, g.s_main));
       HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
+      // the rest of column k+1: TRSM(k+1) needs it
+      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
+      HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
+      if (r1.na > 0) ++upd_launches;
+      if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
       if (r2.na + r2.nb > 0) {
         launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
         ++upd_launches;

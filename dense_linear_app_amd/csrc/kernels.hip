@@ -450,6 +450,19 @@ struct BlockMap {
 __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, int na, int offb, int nb,
                                                  int nbm, int blocks_a, BlockMap &out) {
   int b = blockIdx.x;
+  if (na == 0 && nb == 1) {
+    // one diagonal tile on its own (the SYRK that releases the next POTRF): nothing to share
+    // through an L2, so its blocks go round-robin over all XCDs, one workgroup per CU
+    int macro = b, mj = 0;
+    while (macro >= nbm - mj) {
+      macro -= nbm - mj;
+      ++mj;
+    }
+    out.ij = list[offb];
+    out.mj = mj;
+    out.mi = mj + macro;
+    return true;
+  }
   if (b < blocks_a) {
     const int MT = nbm * nbm, G = MT >= 64 ? 1 : 64 / MT;
     const int x = b & 7, s = b >> 3;
@@ -614,9 +627,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A
 //     that builds the diagonal block's inverse (wave 0, one column per lane);
 //   phase B (all waves): trailing update of the 16x16 blocks below/right with the
 //     16x16x4 MFMA straight out of LDS.
-// Then the inverse of the whole factor, in place over the strictly-lower blocks
-// (block version of LAPACK dtrti2 'L': block columns from the last to the first, the
-// untouched strictly-upper blocks serve as scratch), again on the MFMA.
+// Then the inverse of the whole factor, in place over the strictly-lower blocks, by recursive
+// halving (invert_level), again on the MFMA.
 // factor = 0: only invert an already factored block.  The strict upper triangle of A
 // is never read or written.
 // ------------------------------------------------------------------------------
@@ -680,10 +692,69 @@ __device__ __forceinline__ void sqrt_rsqrt(float d, float &s, float &rinv) {
   rinv = 1.0f / s;
 }
 
+// One level of the recursive inversion of the lower block-triangular factor (16x16 blocks; the
+// diagonal blocks' inverses are in Wd, everything below the diagonal in S).  At half-size H the
+// 8 x 8 block matrix splits into 8 / 2H groups [[L11, 0], [L21, L22]] whose W11 = inv(L11) and
+// W22 = inv(L22) are already in place; W21 = -W22 L21 W11 in two stages, four tasks each (one per
+// wave): T = L21 W11 by rows (a task reads only its own row of L21, holds the H results in
+// registers and overwrites that row), then W21 = -W22 T by columns (same argument).  Three
+// levels, H = 1, 2, 4: depth 31 block products instead of the 7 dependent block-column sweeps
+// of the in-place dtrti2 order.
+template <typename T, int H>
+__device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
+  using acc_t = typename Tr<T>::acc_t;
+  const int lane = threadIdx.x & 63, lo = lane & 15;
+  const int g0 = (w / H) * 2 * H, o = w % H;
+  acc_t acc[H];
+  {
+    const int a = g0 + H + o;
+#pragma unroll
+    for (int bb = 0; bb < H; ++bb) {
+      const int b = g0 + bb;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[bb][reg] = T(0);
+      for (int c = b; c < g0 + H; ++c) {
+        const T *Sec = (c == b) ? Wd[c] : S + db_off(c, b);
+        mm16<T>(acc[bb], S + db_off(a, c), 1, DB_LD, Sec, 1, (c == b) ? 16 : DB_LD, false);
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < H; ++bb) {
+      T *Cb = S + db_off(a, g0 + bb);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[bb][reg];
+    }
+  }
+  __syncthreads();
+  {
+    const int b = g0 + o;
+#pragma unroll
+    for (int aa = 0; aa < H; ++aa) {
+      const int a = g0 + H + aa;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[aa][reg] = T(0);
+      for (int c = g0 + H; c <= a; ++c) {
+        const T *Fp = (c == a) ? Wd[a] : S + db_off(a, c);
+        mm16<T>(acc[aa], Fp, 1, (c == a) ? 16 : DB_LD, S + db_off(c, b), 1, DB_LD, true);
+      }
+    }
+#pragma unroll
+    for (int aa = 0; aa < H; ++aa) {
+      T *Cb = S + db_off(g0 + H + aa, b);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[aa][reg];
+    }
+  }
+  __syncthreads();
+}
+
 template <typename T>
 struct DiagLds {
   T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
   T Wd[DB_NP][16 * 16];
+  T Lcol[16 * 16];  // phase A: the finished columns of the 16x16 factor being built ...
+  T Lrinv[16];      // ... the reciprocals of its pivots ...
+  int colready;     // ... and how many columns have been published (16 p + columns of panel p)
   int failed;
 };
 
@@ -698,26 +769,26 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   T(*Wd)[NB * NB] = L.Wd;
   int &failed = L.failed;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
-  // Load the lower triangle: 16 independent loads in flight per thread and pass (the kernel
-  // usually runs beside a trailing update that keeps the memory system busy, where one
-  // dependent round trip per element cost 5x the whole factorisation).
+  // Global <-> LDS: thread t owns row (t & 127) and block columns 4 (t >> 7) .. +3; per 16x16
+  // block the 16 elements of its row are one base address + constant strides on both sides
+  // (no per-element index arithmetic), 16 independent accesses in flight, rows of consecutive
+  // threads contiguous in global memory.
+  const int gi = t & (n - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
 #pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int c = gc0; c < gc0 + 4; ++c) {
+    if (gr < c) continue;
     T v[16];
+    const T *src = A + gi + (size_t)(NB * c) * ld;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = t + 256 * (16 * pass + u);
-      const int i = idx & (n - 1), j = idx >> 7;
-      v[u] = (i >= j) ? A[i + (size_t)j * ld] : T(0);
-    }
+    for (int u = 0; u < 16; ++u) v[u] = (gr > c || (gi & 15) >= u) ? src[(size_t)u * ld] : T(0);
+    T *dst = S + db_off(gr, c) + (gi & 15);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = t + 256 * (16 * pass + u);
-      const int i = idx & (n - 1), j = idx >> 7;
-      if ((i >> 4) >= (j >> 4)) S[db_idx(i, j)] = v[u];
-    }
+    for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[u];
   }
-  if (t == 0) failed = 0;
+  if (t == 0) {
+    failed = 0;
+    L.colready = 0;
+  }
   __syncthreads();
   if (ph && t == 0) ph[0] = PH_NOW();  // loaded
 
@@ -725,46 +796,76 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
     for (int p = 0; p < NP; ++p) {
       const int j0 = NB * p;
       tl = PH_NOW();
-      // ---- phase A
-      if (w == 0 || (w == 1 && j0 + NB + 64 < n)) {
-        T dd[NB], a[NB];
-        const int myrow = j0 + NB + 64 * w + lane;
-        const bool rowok = myrow < n;
-        const int rr = rowok ? myrow : n - 1;
-        const T *Dp = S + db_off(p, p) + lo;
-        T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
+      // ---- phase A: wave 0 factors the 16x16 diagonal block and publishes each finished
+      // column (and 1/pivot) in LDS; waves 1, 2 (rows below, one row per lane) and wave 3 (the
+      // block's inverse, one column per lane) follow one column behind, picking the multipliers
+      // up as LDS broadcasts.  Only wave 0's pivot chain is on the critical path.
+      {
+        T *Lc = L.Lcol, *Lr = L.Lrinv;
+        const int fbase = NB * p;
+        if (w == 0) {
+          T dd[NB];
+          const T *Dp = S + db_off(p, p) + lo;
 #pragma unroll
-        for (int jj = 0; jj < NB; ++jj) {
-          dd[jj] = Dp[jj * DB_LD];
-          a[jj] = Rp[jj * DB_LD];
-        }
-        int bad = 0;
-#pragma unroll
-        for (int jj = 0; jj < NB; ++jj) {
-          const T d = rlane(dd[jj], jj);
-          if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
-          T sq, rinv;
-          sqrt_rsqrt(d, sq, rinv);
-          dd[jj] = (lo == jj) ? sq : dd[jj] * rinv;
-          a[jj] *= rinv;
-#pragma unroll
-          for (int c = jj + 1; c < NB; ++c) {
-            const T l = rlane(dd[jj], c);  // L(c, jj)
-            dd[c] -= dd[jj] * l;
-            a[c] -= a[jj] * l;
-          }
-        }
-        if (bad) {
-          if (w == 0 && lane == 0) {
-            atomicCAS(info, 0, info_base + j0 + bad);
-            failed = 1;
-          }
-        } else {
-          T *Dw = S + db_off(p, p) + lo;
+          for (int jj = 0; jj < NB; ++jj) dd[jj] = Dp[jj * DB_LD];
+          int bad = 0;
 #pragma unroll
           for (int jj = 0; jj < NB; ++jj) {
-            if (rowok) Rp[jj * DB_LD] = a[jj];
-            if (w == 0 && lane < NB && jj <= lane) Dw[jj * DB_LD] = dd[jj];
+            const T d = rlane(dd[jj], jj);
+            if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
+            T sq, rinv;
+            sqrt_rsqrt(d, sq, rinv);
+            dd[jj] = (lo == jj) ? sq : dd[jj] * rinv;
+            if (lane <= NB) *(lane < NB ? &Lc[jj * NB + lane] : &Lr[jj]) = (lane < NB) ? dd[jj] : rinv;
+            // DS operations of one wave execute in order: the flag lands after the column
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            // L(c, jj): the next pivot's column straight from the lane (critical chain), the others
+            // as LDS broadcasts of the column just published (off the chain, no SGPR traffic)
+#pragma unroll
+            for (int c = jj + 1; c < NB; ++c)
+              dd[c] -= dd[jj] * ((c == jj + 1) ? rlane(dd[jj], c) : Lc[jj * NB + c]);
+          }
+          if (bad) {
+            if (lane == 0) {
+              atomicCAS(info, 0, info_base + j0 + bad);
+              failed = 1;
+            }
+          } else if (lane < NB) {
+            T *Dw = S + db_off(p, p) + lo;
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj)
+              if (jj <= lane) Dw[jj * DB_LD] = dd[jj];
+          }
+        } else {
+          const int myrow = j0 + NB + 64 * (w - 1) + lane;
+          const bool rows = (w < 3), rowok = rows && myrow < n;
+          const bool active = rows ? (j0 + NB + 64 * (w - 1) < n) : true;
+          if (active) {
+            T a[NB];
+            const int rr = rowok ? myrow : n - 1;
+            T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) a[jj] = rows ? Rp[jj * DB_LD] : ((lo == jj) ? T(1) : T(0));
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) {
+              while (__hip_atomic_load(&L.colready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < fbase + jj + 1)
+                __builtin_amdgcn_s_sleep(1);
+              asm volatile("" ::: "memory");
+              a[jj] *= Lr[jj];
+#pragma unroll
+              for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * Lc[jj * NB + c];
+            }
+            if (rows) {
+              if (rowok) {
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) Rp[jj * DB_LD] = a[jj];
+              }
+            } else if (lane < NB) {
+#pragma unroll
+              for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = a[jj];
+            }
           }
         }
       }
@@ -794,99 +895,66 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       ph[2] = tB;
     }
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {  // 16 LDS reads in flight, then 16 stores
+    for (int c = gc0; c < gc0 + 4; ++c) {
+      if (gr < c) continue;
       T v[16];
+      const T *src = S + db_off(gr, c) + (gi & 15);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = t + 256 * (16 * pass + u);
-        const int i = idx & (n - 1), j = idx >> 7;
-        v[u] = (i >= j) ? S[db_idx(i, j)] : T(0);
-      }
+      for (int u = 0; u < 16; ++u) v[u] = src[u * DB_LD];
+      T *dst = A + gi + (size_t)(NB * c) * ld;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = t + 256 * (16 * pass + u);
-        const int i = idx & (n - 1), j = idx >> 7;
-        if (i >= j) A[i + (size_t)j * ld] = v[u];
-      }
+      for (int u = 0; u < 16; ++u)
+        if (gr > c || (gi & 15) >= u) dst[(size_t)u * ld] = v[u];
     }
   }
   if (ph && t == 0) ph[3] = PH_NOW();  // L stored
   // inverses of the eight 16x16 diagonal blocks (one column per lane, forward substitution
   // with L(c,jj) broadcast by v_readlane), two blocks per wave, all waves in parallel
-  for (int p = w; p < NP; p += 4) {
-    T dd[NB], x[NB];
-    const T *Dp = S + db_off(p, p) + lo;
+  if (!factor) {  // (when factoring, wave 3 built them during phase A)
+    for (int p = w; p < NP; p += 4) {
+      T x[NB];
+      const T *Db = S + db_off(p, p);  // L(c, jj) at Db[c + jj * DB_LD]: read as LDS broadcasts
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) {
-      dd[jj] = Dp[jj * DB_LD];
-      x[jj] = (lo == jj) ? T(1) : T(0);
-    }
+      for (int jj = 0; jj < NB; ++jj) x[jj] = (lo == jj) ? T(1) : T(0);
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) {
-      const T rinv = T(1) / rlane(dd[jj], jj);
-      x[jj] *= rinv;
+      for (int jj = 0; jj < NB; ++jj) {
+        x[jj] *= T(1) / Db[jj + jj * DB_LD];
 #pragma unroll
-      for (int c = jj + 1; c < NB; ++c) x[c] -= x[jj] * rlane(dd[jj], c);
-    }
-    if (lane < NB) {
+        for (int c = jj + 1; c < NB; ++c) x[c] -= x[jj] * Db[c + jj * DB_LD];
+      }
+      if (lane < NB) {
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
+        for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
+      }
     }
   }
   __syncthreads();
   if (ph && t == 0) ph[4] = PH_NOW();  // Wd done
 
-  // ---- inverse of the whole factor, block column j from NP-2 down to 0 (in place):
-  //   Y(i) = sum_{k=j+1..i} W(i,k) L(k,j)   (kept in registers until every wave has read L(:,j))
-  //   W(i,j) = -Y(i) W(j,j)                  (overwrites L(i,j))
-  for (int j = NP - 2; j >= 0; --j) {
-    typename Tr<T>::acc_t y[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = j + 1 + w + 4 * u;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) y[u][reg] = T(0);
-      if (i < NP) {
-        for (int k = j + 1; k < i; ++k)
-          mm16<T>(y[u], S + db_off(i, k), 1, DB_LD, S + db_off(k, j), 1, DB_LD, false);
-        mm16<T>(y[u], Wd[i], 1, NB, S + db_off(i, j), 1, DB_LD, false);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = j + 1 + w + 4 * u;
-      if (i < NP) {
-        T *Wb = S + db_off(i, j);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * DB_LD] = y[u][reg];
-        typename Tr<T>::acc_t acc;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) acc[reg] = T(0);
-        mm16<T>(acc, Wb, 1, DB_LD, Wd[j], 1, NB, true);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Wb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[reg];
-      }
-    }
-    __syncthreads();
-  }
+  // ---- inverse of the whole factor, in place over the strictly-lower blocks
+  invert_level<T, 1>(S, Wd, w);
+  invert_level<T, 2>(S, Wd, w);
+  invert_level<T, 4>(S, Wd, w);
   if (ph && t == 0) ph[5] = PH_NOW();  // phase C done
 #undef PH_NOW
 #pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int c = gc0; c < gc0 + 4; ++c) {  // winv: full 128 x 128, zero above the diagonal
     T v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = t + 256 * (16 * pass + u);
-      const int i = idx & (n - 1), j = idx >> 7;
-      v[u] = T(0);
-      if ((i >> 4) == (j >> 4))
-        v[u] = Wd[i >> 4][(i & 15) + (j & 15) * NB];
-      else if (i > j)
-        v[u] = S[db_idx(i, j)];
-    }
+    for (int u = 0; u < 16; ++u) v[u] = T(0);
+    if (gr == c) {
+      const T *src = Wd[c] + (gi & 15);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) winv[t + 256 * (16 * pass + u)] = v[u];
+      for (int u = 0; u < 16; ++u)
+        if ((gi & 15) >= u) v[u] = src[u * NB];
+    } else if (gr > c) {
+      const T *src = S + db_off(gr, c) + (gi & 15);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[u * DB_LD];
+    }
+    T *dst = winv + gi + (size_t)(NB * c) * n;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dst[(size_t)u * n] = v[u];
   }
 }
 
@@ -1140,8 +1208,9 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   offb -= off;  // the kernels index from d_list + off
   const int nbm = C.mb / MACRO, MT = nbm * nbm, MTd = nbm * (nbm + 1) / 2;
   const int Ga = MT >= 64 ? 1 : 64 / MT, Gd = MTd >= 64 ? 1 : 64 / MTd;
-  const long blocks_a = (long)((na + 8 * Ga - 1) / (8 * Ga)) * 8 * Ga * MT;
-  const long blocks_b = (long)((nb + 8 * Gd - 1) / (8 * Gd)) * 8 * Gd * MTd;
+  long blocks_a = (long)((na + 8 * Ga - 1) / (8 * Ga)) * 8 * Ga * MT;
+  long blocks_b = (long)((nb + 8 * Gd - 1) / (8 * Gd)) * 8 * Gd * MTd;
+  if (na == 0 && nb == 1) blocks_a = 0, blocks_b = MTd;  // single diagonal tile: spread, no padding
   const dim3 grid((unsigned)(blocks_a + blocks_b)), blk(256);
   if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
     k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, g_ablate & 255);
