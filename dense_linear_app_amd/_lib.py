@@ -51,6 +51,8 @@ def lib() -> C.CDLL:
         "chol_lange_tile": ([i, vp, C.POINTER(d)], i),
         "chol_lauum_tile": ([i, vp], i),
         "chol_geadd_tile": ([i, d, vp, d, vp], i),
+        "chol_potrs_tile": ([i, vp, vp], i),
+        "chol_posv_tile": ([i, vp, vp], i),
         "chol_lapack_to_tile": ([vp, i, vp], i),
         "chol_tile_to_lapack": ([vp, vp, i], i),
         "chol_tile_upload": ([vp, i, i, vp], i),

@@ -201,6 +201,18 @@ def CHAMELEON_dgeadd_Tile(trans: int, alpha: float, A: Desc, beta: float, B: Des
     return check("chol_geadd_tile", lib().chol_geadd_tile(trans, float(alpha), A.handle, float(beta), B.handle))
 
 
+def CHAMELEON_dpotrs_Tile(uplo: int, A: Desc, B: Desc) -> int:
+    """B <- A^{-1} B with A = L L^T already factored by CHAMELEON_dpotrf_Tile (ChamLower)."""
+    return check("chol_potrs_tile", lib().chol_potrs_tile(uplo, A.handle, B.handle))
+
+
+def CHAMELEON_dposv_Tile(uplo: int, A: Desc, B: Desc) -> int:
+    """Factor A and solve A X = B in place of B.  Returns info (> 0: A is not positive definite)."""
+    return check("chol_posv_tile", lib().chol_posv_tile(uplo, A.handle, B.handle))
+
+
+CHAMELEON_spotrs_Tile = CHAMELEON_dpotrs_Tile
+CHAMELEON_sposv_Tile = CHAMELEON_dposv_Tile
 CHAMELEON_slacpy_Tile = CHAMELEON_dlacpy_Tile
 CHAMELEON_slange_Tile = CHAMELEON_dlange_Tile
 CHAMELEON_slauum_Tile = CHAMELEON_dlauum_Tile

@@ -397,6 +397,63 @@ static int gemm_impl(double alpha, chol_desc *A, chol_desc *B, double beta, chol
   return 0;
 }
 
+// ---------------------------------------------------------------- solve with the factor
+// X <- A^{-1} B for A = L L^T already factored (CHAMELEON_dpotrs_Tile(ChamLower, A, B)).
+// The kernels of this library are the right-sided NT forms the factorisation needs
+// (X = A L^{-T}, C -= A B^T), so the solve runs on Z = B^T:
+//   forward   Z(:,k) <- Z(:,k) L(k,k)^{-T};  Z(:,i) -= Z(:,k) L(i,k)^T, i > k      (L Y = B)
+//   backward  Z(:,k) <- Z(:,k) L(k,k)^{-1};  Z(:,i) -= Z(:,k) L(k,i),   i < k      (L^T X = Y)
+// the backward sweep's operands being transposed tiles (L(k,k)^{-T} from a TRSM of the identity,
+// L(k,i)^T from a tile transpose) so that every product is again A B^T.
+template <typename T>
+int potrs_impl(chol_desc *A, chol_desc *B) {
+  const int nt = A->nt, nr = B->nt, mb = A->mbi;
+  const long bs = A->bsizi;
+  const size_t tb = (size_t)bs * sizeof(T);
+  T *La = reinterpret_cast<T *>(A->mat), *Bm = reinterpret_cast<T *>(B->mat);
+  T *scr = nullptr;
+  if (hipMalloc(&scr, ((size_t)nr * nt + 3) * tb) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CHOL_ERR_OUT_OF_MEMORY, "potrs_tile: scratch allocation failed");
+  }
+  T *Z = scr, *Wt = scr + (size_t)nr * nt * bs, *Tt = Wt + bs, *tmp = Tt + bs;
+  hipStream_t s = g.s_main;
+  T *winv = reinterpret_cast<T *>(g.winv);
+  auto Ltile = [&](int i, int j) { return La + ((long)i + (long)j * A->lmt) * bs; };
+  auto Ztile = [&](int r, int i) { return Z + ((long)r + (long)i * nr) * bs; };
+  // Z(r,i) = B(i,r)^T
+  for (int r = 0; r < nr; ++r)
+    launch_tiles_transpose<T>(s, Bm + (long)r * B->lmt * bs, bs, Ztile(r, 0), (long)nr * bs, mb, nt);
+  for (int k = 0; k < nt; ++k) {  // forward
+    launch_invert_diag<T>(s, Ltile(k, k), mb, winv);
+    launch_trsm_panel<T>(s, Ztile(0, k), bs, nr, Ltile(k, k), winv, mb, T(1));
+    for (int i = k + 1; i < nt; ++i)
+      for (int r = 0; r < nr; ++r)
+        launch_gemm_nt_tile<T>(s, Ztile(r, k), Ltile(i, k), Ztile(r, i), mb, T(-1), T(1), false);
+  }
+  for (int k = nt - 1; k >= 0; --k) {  // backward
+    HIPCHECK(hipMemsetAsync(Wt, 0, tb, s));
+    launch_pad_identity<T>(s, Wt, 0, mb);
+    launch_invert_diag<T>(s, Ltile(k, k), mb, winv);
+    launch_trsm_panel<T>(s, Wt, bs, 1, Ltile(k, k), winv, mb, T(1));  // Wt = L(k,k)^{-T}
+    for (int r = 0; r < nr; ++r) {
+      launch_gemm_nt_tile<T>(s, Ztile(r, k), Wt, tmp, mb, T(1), T(0), false);  // Z(r,k) L(k,k)^{-1}
+      HIPCHECK(hipMemcpyAsync(Ztile(r, k), tmp, tb, hipMemcpyDeviceToDevice, s));
+    }
+    for (int i = 0; i < k; ++i) {
+      launch_tiles_transpose<T>(s, Ltile(k, i), bs, Tt, bs, mb, 1);  // Tt = L(k,i)^T
+      for (int r = 0; r < nr; ++r)
+        launch_gemm_nt_tile<T>(s, Ztile(r, k), Tt, Ztile(r, i), mb, T(-1), T(1), false);
+    }
+  }
+  for (int r = 0; r < nr; ++r)  // B(i,r) = Z(r,i)^T
+    launch_tiles_transpose<T>(s, Ztile(r, 0), (long)nr * bs, Bm + (long)r * B->lmt * bs, bs, mb, nt);
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(scr);
+  if (e != hipSuccess) return fail_hip(e, "potrs_tile", __LINE__);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -529,9 +586,9 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     // ragged order and/or a tile edge that is not a multiple of 128 (the reference's sweep
     // uses NB = 192 ... 448): the library keeps its own image with tiles rounded up to 128
     // and the identity outside the matrix.  Needs library-owned storage on one process.
-    if (mat || p * q != 1 || mb != nb || lm != ln)
+    if (mat || p * q != 1 || mb != nb)
       return delete d, fail(CHOL_ERR_NOT_SUPPORTED,
-                            "desc_create: ragged / non-128 tiles need mat == NULL, p*q == 1, a square matrix");
+                            "desc_create: ragged / non-128 tiles need mat == NULL, p*q == 1, square tiles");
     d->mbi = roundup(mb, MACRO);
     d->bsizi = d->mbi * d->mbi;
     d->padded = true;
@@ -552,7 +609,7 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     }
     d->owns = true;
     d->on_device = true;
-    if (d->padded) {  // zero everywhere, identity on the diagonal tiles' diagonals
+    if (d->padded && lm == ln) {  // zero everywhere, identity on the diagonal tiles' diagonals
       const LocalMat Lm = local_mat(d, d->mat);
       if (dtype == CHOL_REAL_DOUBLE)
         launch_plgsy<double>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
@@ -820,6 +877,31 @@ int chol_lauum_tile(int uplo, chol_desc_t *A) {
   (void)hipFree(tmp);
   if (e != hipSuccess) return fail_hip(e, "lauum_tile", __LINE__);
   return 0;
+}
+
+// ---------------------------------------------------------------- solve with the factor
+int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrs_tile before chol_init");
+  if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: only ChamLower");
+  int rc = resident_whole("potrs_tile", A);
+  if (rc) return rc;
+  rc = resident_whole("potrs_tile", B);
+  if (rc) return rc;
+  if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrs_tile: A is not square");
+  if (B->lm != A->lm || B->mb != A->mb || B->mbi != A->mbi || B->dtype != A->dtype)
+    return fail(-3, "potrs_tile: B must have A's order, tile size and type");
+  if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: stored tile edge must be a multiple of 64");
+  if ((size_t)(A->mbi / MACRO) * MACRO * MACRO * A->esize > g.winv_bytes)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: tile size above 4096");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return A->dtype == CHOL_REAL_DOUBLE ? potrs_impl<double>(A, B) : potrs_impl<float>(A, B);
+}
+
+int chol_posv_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
+  if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "posv_tile: only ChamLower");
+  const int info = chol_potrf_tile(uplo, A);
+  if (info != 0) return info;  // > 0: not positive definite, B untouched (LAPACK dposv)
+  return chol_potrs_tile(uplo, A, B);
 }
 
 // valid extent of tile (I,J) inside the matrix (edge tiles are smaller)

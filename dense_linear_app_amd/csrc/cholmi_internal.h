@@ -111,6 +111,10 @@ void launch_lange(hipStream_t s, const TileGeo &g, int kind, const T *A, double 
 template <typename T>
 void launch_lauum_lower(hipStream_t s, const T *L, T *out, int nt, int mbs);
 
+// out-of-place transposes of `count` mb x mb tiles (mb % 64 == 0)
+template <typename T>
+void launch_tiles_transpose(hipStream_t s, const T *in, long istride, T *out, long ostride, int mb, int count);
+
 // register-only MFMA stream (blocks x 256 threads, 16 MFMA per wave per iteration)
 template <typename T>
 void launch_mfma_probe(hipStream_t s, T *out, int blocks, int iters);

@@ -210,6 +210,24 @@ __global__ __launch_bounds__(256) void k_lauum_lower(const T *__restrict__ L, T 
       }
 }
 
+// out = in^T for `count` independent mb x mb tiles (tile q of `in` at in + q*istride, of `out` at
+// out + q*ostride, elements); mb a multiple of 64.  64 x 64 sub-blocks through LDS, both sides
+// coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void k_tiles_transpose(const T *__restrict__ in, long istride, T *__restrict__ out,
+                                                         long ostride, int mb) {
+  __shared__ T sa[64][65];
+  const int nsub = mb / 64;
+  const int q = blockIdx.x / (nsub * nsub), sub = blockIdx.x % (nsub * nsub);
+  const int si = sub % nsub, sj = sub / nsub;
+  const T *ta = in + q * istride + si * 64 + (long)sj * 64 * mb;
+  T *tb = out + q * ostride + sj * 64 + (long)si * 64 * mb;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) sa[c][tx] = ta[tx + (long)c * mb];
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) tb[tx + (long)c * mb] = sa[tx][c];
+}
+
 inline int grid_for_elems(long total) { return (int)std::min<long>(65536, (total + 255) / 256); }
 
 }  // namespace
@@ -255,11 +273,18 @@ void launch_lauum_lower(hipStream_t s, const T *L, T *out, int nt, int mbs) {
   if (blocks) k_lauum_lower<T><<<(unsigned)blocks, 256, 0, s>>>(L, out, nt, mbs);
 }
 
+template <typename T>
+void launch_tiles_transpose(hipStream_t s, const T *in, long istride, T *out, long ostride, int mb, int count) {
+  const int nsub = mb / 64;
+  if (count > 0) k_tiles_transpose<T><<<(unsigned)(count * nsub * nsub), 256, 0, s>>>(in, istride, out, ostride, mb);
+}
+
 #define INSTANTIATE_V(T)                                                                     \
   template void launch_lacpy<T>(hipStream_t, const TileGeo &, int, const T *, T *);          \
   template void launch_geadd<T>(hipStream_t, const TileGeo &, double, const T *, double, T *); \
   template void launch_lange<T>(hipStream_t, const TileGeo &, int, const T *, double *);     \
-  template void launch_lauum_lower<T>(hipStream_t, const T *, T *, int, int);
+  template void launch_lauum_lower<T>(hipStream_t, const T *, T *, int, int);                \
+  template void launch_tiles_transpose<T>(hipStream_t, const T *, long, T *, long, int, int);
 INSTANTIATE_V(double)
 INSTANTIATE_V(float)
 

@@ -136,6 +136,13 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value);
 int chol_lauum_tile(int uplo, chol_desc_t *A);
 int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *B);
 
+/* The step after the factor (not called by the reference):
+ *   CHAMELEON_dpotrs_Tile(ChamLower, A, B)   B <- A^{-1} B with A = L L^T already factored
+ *   CHAMELEON_dposv_Tile(ChamLower, A, B)    factor A, then solve; info > 0: A not SPD, B untouched
+ * A: n x n, B: n x nrhs, device-resident single-process descriptors with the same tile size. */
+int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B);
+int chol_posv_tile(int uplo, chol_desc_t *A, chol_desc_t *B);
+
 /* CHAMELEON_Lapack_to_Tile / Tile_to_Lapack equivalents (host LAPACK layout
  * <-> descriptor storage); single-process descriptors only. */
 int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *desc);

@@ -260,3 +260,43 @@ def test_v6_validation_as_written_reproduces_the_reference_csv(cham, N):
         assert ch.residual_plgsy(dA, float(N), 42) <= 1e-13  # the factor itself is at rounding level
         ch.CHAMELEON_Desc_Destroy(dA)
         ch.CHAMELEON_Desc_Destroy(dO)
+
+
+@pytest.mark.parametrize("N,B,nrhs,dt", [(1024, 256, 256, "f64"), (1536, 512, 1024, "f64"), (1000, 192, 300, "f64"),
+                                          (2048, 128, 128, "f64"), (1024, 256, 512, "f32")])
+def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
+    """The step after the factor: CHAMELEON_dpotrs_Tile / dposv_Tile, lower, on
+    tile-multiple, ragged and odd-tile shapes; checked against numpy.linalg.solve."""
+    ch = cham
+    cdt = ch.ChamRealDouble if dt == "f64" else ch.ChamRealFloat
+    npdt = np.float64 if dt == "f64" else np.float32
+    tol = 1e-12 if dt == "f64" else 2e-4
+    A = orc.plgsy_matrix(N, float(N), 42)
+    rng = np.random.default_rng(11)
+    Bm = np.asfortranarray(rng.standard_normal((N, nrhs)))
+    X = np.linalg.solve(A, Bm)
+    dA = ch.CHAMELEON_Desc_Create(None, cdt, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+    dB = ch.CHAMELEON_Desc_Create(None, cdt, B, B, B * B, N, nrhs, 0, 0, N, nrhs, 1, 1)
+    # potrf then potrs
+    dA.from_lapack(A.astype(npdt))
+    dB.from_lapack(Bm.astype(npdt))
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, dA) == 0
+    assert ch.CHAMELEON_dpotrs_Tile(ch.ChamLower, dA, dB) == 0
+    got = dB.to_lapack().astype(np.float64)
+    assert got.shape == (N, nrhs)
+    assert np.abs(got - X).max() / np.abs(X).max() <= tol
+    assert np.linalg.norm(A @ got - Bm) / (np.linalg.norm(A) * np.linalg.norm(got)) <= (1e-15 if dt == "f64" else 1e-6)
+    # posv in one call; a second solve with the same factor gives the same answer
+    dA.from_lapack(A.astype(npdt))
+    dB.from_lapack(Bm.astype(npdt))
+    assert ch.CHAMELEON_dposv_Tile(ch.ChamLower, dA, dB) == 0
+    assert np.array_equal(dB.to_lapack().astype(np.float64), got)
+    # not positive definite: info > 0, B untouched
+    M = A.copy(order="F")
+    M[N // 2, N // 2] = -1.0
+    dA.from_lapack(M.astype(npdt))
+    dB.from_lapack(Bm.astype(npdt))
+    assert ch.CHAMELEON_dposv_Tile(ch.ChamLower, dA, dB) == N // 2 + 1
+    assert np.array_equal(dB.to_lapack(), Bm.astype(npdt))
+    with pytest.raises(ch.CholmiError):
+        ch.CHAMELEON_dpotrs_Tile(ch.ChamUpper, dA, dB)
