@@ -748,6 +748,31 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   __syncthreads();
 }
 
+// Wait until the LDS counter at byte address `lds_addr` reaches `target` (phase A of the
+// diagonal-block kernel: columns published by wave 0).  One opaque instruction sequence on
+// purpose: written as a C loop, sixteen unrolled copies of it gave the register allocator a
+// control-flow graph on which the kernel needed 400 VGPRs instead of 256.  Bounded (the producer
+// needs ~1 us per column even beside a running update; the bound is ~1 ms): a logic error shows up
+// as a wrong result in the tests, never as a hung GPU.
+__device__ __forceinline__ void wait_published(unsigned lds_addr, int target) {
+  int v, n = 0x3fff;
+  asm volatile(
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
+      "s_cbranch_vccz 2f\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_eq_u32 %1, 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "s_sleep 1\n\t"
+      "s_branch 1b\n\t"
+      "2:"
+      : "=&v"(v), "+s"(n)
+      : "v"(lds_addr), "s"(target)
+      : "vcc", "scc", "memory");
+}
+
 template <typename T>
 struct DiagLds {
   T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
@@ -768,7 +793,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   T *S = L.S;
   T(*Wd)[NB * NB] = L.Wd;
   int &failed = L.failed;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lo = lane & 15;
+  const int t = threadIdx.x, lane = t & 63, lo = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform by construction: scalar branches
   // Global <-> LDS: thread t owns row (t & 127) and block columns 4 (t >> 7) .. +3; per 16x16
   // block the 16 elements of its row are one base address + constant strides on both sides
   // (no per-element index arithmetic), 16 independent accesses in flight, rows of consecutive
@@ -801,11 +827,20 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       // block's inverse, one column per lane) follow one column behind, picking the multipliers
       // up as LDS broadcasts.  Only wave 0's pivot chain is on the critical path.
       {
-        T *Lc = L.Lcol, *Lr = L.Lrinv;
+        // LDS pointers with an opaque base: the 272 constant addresses below then encode as one
+        // base register + immediate offsets instead of one hoisted VGPR each
+        typedef __attribute__((address_space(3))) T lds_t;
+        lds_t *Lc = (lds_t *)L.Lcol, *Lr = (lds_t *)L.Lrinv;
+        asm volatile("" : "+v"(Lc), "+v"(Lr));
         const int fbase = NB * p;
+        // lane ids made opaque per panel: otherwise every lane mask, select and address of the
+        // unrolled column code below is hoisted out of the panel loop and kept in registers for
+        // its whole length (that alone cost > 100 VGPRs and most of the SGPR spills)
+        int lane_ = lane, lo_ = lo;
+        asm volatile("" : "+v"(lane_), "+v"(lo_));
         if (w == 0) {
           T dd[NB];
-          const T *Dp = S + db_off(p, p) + lo;
+          const T *Dp = S + db_off(p, p) + lo_;
 #pragma unroll
           for (int jj = 0; jj < NB; ++jj) dd[jj] = Dp[jj * DB_LD];
           int bad = 0;
@@ -815,44 +850,44 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
             T sq, rinv;
             sqrt_rsqrt(d, sq, rinv);
-            dd[jj] = (lo == jj) ? sq : dd[jj] * rinv;
-            if (lane <= NB) *(lane < NB ? &Lc[jj * NB + lane] : &Lr[jj]) = (lane < NB) ? dd[jj] : rinv;
+            dd[jj] = (lo_ == jj) ? sq : dd[jj] * rinv;
+            if (lane_ < NB) Lc[jj * NB + lane_] = dd[jj];
+            if (lane_ == NB) Lr[jj] = rinv;
             // DS operations of one wave execute in order: the flag lands after the column
             asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane_ == 0) __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
-            // L(c, jj): the next pivot's column straight from the lane (critical chain), the others
+            // L(c, jj): the next pivot's column straight from the lane_ (critical chain), the others
             // as LDS broadcasts of the column just published (off the chain, no SGPR traffic)
 #pragma unroll
             for (int c = jj + 1; c < NB; ++c)
               dd[c] -= dd[jj] * ((c == jj + 1) ? rlane(dd[jj], c) : Lc[jj * NB + c]);
           }
           if (bad) {
-            if (lane == 0) {
+            if (lane_ == 0) {
               atomicCAS(info, 0, info_base + j0 + bad);
               failed = 1;
             }
-          } else if (lane < NB) {
-            T *Dw = S + db_off(p, p) + lo;
+          } else if (lane_ < NB) {
+            T *Dw = S + db_off(p, p) + lo_;
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj)
-              if (jj <= lane) Dw[jj * DB_LD] = dd[jj];
+              if (jj <= lane_) Dw[jj * DB_LD] = dd[jj];
           }
         } else {
-          const int myrow = j0 + NB + 64 * (w - 1) + lane;
+          const int myrow = j0 + NB + 64 * (w - 1) + lane_;
           const bool rows = (w < 3), rowok = rows && myrow < n;
           const bool active = rows ? (j0 + NB + 64 * (w - 1) < n) : true;
           if (active) {
+            const unsigned flag_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&L.colready;
             T a[NB];
             const int rr = rowok ? myrow : n - 1;
             T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
 #pragma unroll
-            for (int jj = 0; jj < NB; ++jj) a[jj] = rows ? Rp[jj * DB_LD] : ((lo == jj) ? T(1) : T(0));
+            for (int jj = 0; jj < NB; ++jj) a[jj] = rows ? Rp[jj * DB_LD] : ((lo_ == jj) ? T(1) : T(0));
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) {
-              while (__hip_atomic_load(&L.colready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < fbase + jj + 1)
-                __builtin_amdgcn_s_sleep(1);
-              asm volatile("" ::: "memory");
+              wait_published(flag_lds, fbase + jj + 1);
               a[jj] *= Lr[jj];
 #pragma unroll
               for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * Lc[jj * NB + c];
@@ -862,9 +897,9 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #pragma unroll
                 for (int jj = 0; jj < NB; ++jj) Rp[jj * DB_LD] = a[jj];
               }
-            } else if (lane < NB) {
+            } else if (lane_ < NB) {
 #pragma unroll
-              for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = a[jj];
+              for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane_ * NB] = a[jj];
             }
           }
         }
@@ -960,8 +995,10 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 
 // dbg (diagnostic, may be null): dbg[0] = running slot counter, then per launch the
 // workgroup's own {start, end} in 100 MHz realtime ticks.
+// (256, 2): at most 256 VGPRs, so that a wave fits on a SIMD beside one resident trailing-update
+// wave (244 VGPRs); otherwise the kernel has to wait for a whole CU to drain.
 template <typename T>
-__global__ __launch_bounds__(256) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
+__global__ __launch_bounds__(256, 2) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
                                                     int info_base, int factor,
                                                     unsigned long long *dbg, int *ytab) {
   __shared__ DiagLds<T> L;
