@@ -773,6 +773,84 @@ __device__ __forceinline__ void wait_published(unsigned lds_addr, int target) {
       : "vcc", "scc", "memory");
 }
 
+// Consumer side of phase A: fetch column `jj` of the 16x16 factor (16 values), 1/pivot and the
+// publication counter in ONE LDS round trip and retry until the counter says the column was
+// complete when the reads were issued (DS operations execute in order, the counter is read first
+// and written last, so a satisfied counter vouches for the data behind it).  Opaque and bounded for
+// the same reasons as wait_published.
+template <typename T>
+struct ColFetch;
+template <>
+struct ColFetch<double> {
+  typedef double v2_t __attribute__((ext_vector_type(2)));
+  v2_t c[8];
+  double rinv;
+  __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
+  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target) {
+    int v, n = 0x3fff;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %11\n\t"
+        "ds_read2_b64 %1, %12 offset1:1\n\t"
+        "ds_read2_b64 %2, %12 offset0:2 offset1:3\n\t"
+        "ds_read2_b64 %3, %12 offset0:4 offset1:5\n\t"
+        "ds_read2_b64 %4, %12 offset0:6 offset1:7\n\t"
+        "ds_read2_b64 %5, %12 offset0:8 offset1:9\n\t"
+        "ds_read2_b64 %6, %12 offset0:10 offset1:11\n\t"
+        "ds_read2_b64 %7, %12 offset0:12 offset1:13\n\t"
+        "ds_read2_b64 %8, %12 offset0:14 offset1:15\n\t"
+        "ds_read_b64 %9, %13\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_gt_i32_e32 vcc, %14, %0\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_sub_u32 %10, %10, 1\n\t"
+        "s_cmp_eq_u32 %10, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:"
+        : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
+          "=&v"(c[7]), "=&v"(rinv), "+s"(n)
+        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target)
+        : "vcc", "scc", "memory");
+  }
+};
+template <>
+struct ColFetch<float> {
+  typedef float v2_t __attribute__((ext_vector_type(2)));
+  v2_t c[8];
+  float rinv;
+  __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
+  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target) {
+    int v, n = 0x3fff;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %11\n\t"
+        "ds_read2_b32 %1, %12 offset1:1\n\t"
+        "ds_read2_b32 %2, %12 offset0:2 offset1:3\n\t"
+        "ds_read2_b32 %3, %12 offset0:4 offset1:5\n\t"
+        "ds_read2_b32 %4, %12 offset0:6 offset1:7\n\t"
+        "ds_read2_b32 %5, %12 offset0:8 offset1:9\n\t"
+        "ds_read2_b32 %6, %12 offset0:10 offset1:11\n\t"
+        "ds_read2_b32 %7, %12 offset0:12 offset1:13\n\t"
+        "ds_read2_b32 %8, %12 offset0:14 offset1:15\n\t"
+        "ds_read_b32 %9, %13\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_gt_i32_e32 vcc, %14, %0\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_sub_u32 %10, %10, 1\n\t"
+        "s_cmp_eq_u32 %10, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:"
+        : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
+          "=&v"(c[7]), "=&v"(rinv), "+s"(n)
+        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target)
+        : "vcc", "scc", "memory");
+  }
+};
+
 template <typename T>
 struct DiagLds {
   T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
@@ -851,11 +929,13 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             T sq, rinv;
             sqrt_rsqrt(d, sq, rinv);
             dd[jj] = (lo_ == jj) ? sq : dd[jj] * rinv;
-            if (lane_ < NB) Lc[jj * NB + lane_] = dd[jj];
-            if (lane_ == NB) Lr[jj] = rinv;
+            // every lane stores (lanes 16-63 hold copies of rows 0-15; 1/pivot and the counter are
+            // wave-uniform): same address, same value -- no exec-mask region on the critical chain
+            Lc[jj * NB + lo_] = dd[jj];
+            Lr[jj] = rinv;
             // DS operations of one wave execute in order: the flag lands after the column
             asm volatile("" ::: "memory");
-            if (lane_ == 0) __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
             // L(c, jj): the next pivot's column straight from the lane_ (critical chain), the others
             // as LDS broadcasts of the column just published (off the chain, no SGPR traffic)
@@ -885,12 +965,14 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) a[jj] = rows ? Rp[jj * DB_LD] : ((lo_ == jj) ? T(1) : T(0));
+            const unsigned col_lds = (unsigned)(size_t)Lc, rinv_lds = (unsigned)(size_t)Lr;
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) {
-              wait_published(flag_lds, fbase + jj + 1);
-              a[jj] *= Lr[jj];
+              ColFetch<T> cf;
+              cf.fetch(flag_lds, col_lds + jj * NB * (unsigned)sizeof(T), rinv_lds + jj * (unsigned)sizeof(T), fbase + jj + 1);
+              a[jj] *= cf.rinv;
 #pragma unroll
-              for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * Lc[jj * NB + c];
+              for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * cf.at(c);
             }
             if (rows) {
               if (rowok) {
