@@ -246,14 +246,22 @@ int potrf_full_device(chol_desc *d, void *base) {
       const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
       const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
       const bool yield = (double)u1_hi * t_tile < 6.0 * t_panel;
-      // the diagonal tile (k+1,k+1) alone first: POTRF(k+1) needs nothing else
-      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
-      HIPCHECK(hipEventRecord(ev_u1, g.s_main));
+      static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
+      if (yield || split_always) {
+        // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
+        // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
+        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
+        HIPCHECK(hipEventRecord(ev_u1, g.s_main));
+        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
+        HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
+        if (r1.na > 0) ++upd_launches;
+      } else {
+        // the update dwarfs the panel: one launch for the whole column (one tail less per wave)
+        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
+        HIPCHECK(hipEventRecord(ev_u1, g.s_main));
+        HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
+      }
       HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
-      // the rest of column k+1: TRSM(k+1) needs it
-      launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
-      HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
-      if (r1.na > 0) ++upd_launches;
       if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
       if (r2.na + r2.nb > 0) {
         launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
