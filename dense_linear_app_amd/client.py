@@ -203,9 +203,13 @@ def default_task_options() -> ak.TaskOptions:
 
 def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, worker=None,
                      A: Optional[np.ndarray] = None, verbose: bool = False, log=sys.stdout,
-                     device_results: bool = False) -> DagResult:
+                     device_results: bool = False, batched: bool = False) -> DagResult:
     """C2:325-568 (main) as a function.  `worker` defaults to DagCholeskyWorker on the GPU.
-    device_results=True keeps every tile version in HBM between tasks (armonik.DeviceBlob)."""
+    device_results=True keeps every tile version in HBM between tasks (armonik.DeviceBlob).
+    batched=True is the non-blocking client of SURVEY 8f.3: the same tasks, payloads and
+    dependencies, but one create_results_metadata + one submit_tasks + one
+    wait_for_result_availability per phase of a wave (POTRF; all TRSM; all SYRK/GEMM) instead of
+    four blocking calls per task (C2:471-499)."""
     if plane is None:
         plane = ak.ControlPlane(device_results=device_results)
     if worker is None:
@@ -248,7 +252,53 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
         eventsClient.wait_for_result_availability(session_id, [output_id])
         return output_id
 
+    def submit_batch(items: List[tuple]) -> List[str]:
+        """items: (payload_json, data_deps).  One metadata call, one submission, one wait."""
+        if not items:
+            return []
+        names = [f"output/{q}" for q in range(len(items))] + [f"payload/{q}" for q in range(len(items))]
+        ids = resultsClient.create_results_metadata(session_id, names)
+        tcs = []
+        for q, (payload_json, data_deps) in enumerate(items):
+            resultsClient.upload_result_data(session_id, ids[f"payload/{q}"], payload_json)
+            tcs.append(ak.TaskCreation(payload_id=ids[f"payload/{q}"], expected_output_keys=[ids[f"output/{q}"]],
+                                       data_dependencies=sorted(set(data_deps))))
+        opts = taskOptions.copy()
+        opts.partition_id = PARTITION
+        tasksClient.submit_tasks(session_id, tcs, opts)
+        outs = [ids[f"output/{q}"] for q in range(len(items))]
+        eventsClient.wait_for_result_availability(session_id, outs)
+        return outs
+
     t0 = time.perf_counter()
+    if batched:
+        for k in range(Nb):
+            kk = block_id_from_ij(k, k)
+            latest[kk] = submit_batch([(make_payload("POTRF", [latest[kk]], B), [latest[kk]])])[0]
+            counts["POTRF"] += 1
+            Lkk = latest[kk]
+            rows = list(range(k + 1, Nb))
+            outs = submit_batch([(make_payload("TRSM", [Lkk, latest[block_id_from_ij(i, k)]], B),
+                                  [Lkk, latest[block_id_from_ij(i, k)]]) for i in rows])
+            for i, o in zip(rows, outs):
+                latest[block_id_from_ij(i, k)] = o
+            counts["TRSM"] += len(rows)
+            items, keys = [], []
+            for i in rows:
+                Aik = latest[block_id_from_ij(i, k)]
+                for j in range(k + 1, i + 1):
+                    Cij = latest[block_id_from_ij(i, j)]
+                    if i == j:
+                        items.append((make_payload("SYRK", [Cij, Aik], B), [Cij, Aik]))
+                        counts["SYRK"] += 1
+                    else:
+                        Ajk = latest[block_id_from_ij(j, k)]
+                        items.append((make_payload("GEMM", [Cij, Aik, Ajk], B), [Cij, Aik, Ajk]))
+                        counts["GEMM"] += 1
+                    keys.append(block_id_from_ij(i, j))
+            for key, o in zip(keys, submit_batch(items)):
+                latest[key] = o
+        return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane)
     for k in range(Nb):  # C2:506
         if verbose:
             print(f"Wave k={k}", file=log)

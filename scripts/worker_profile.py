@@ -6,13 +6,13 @@ from dense_linear_app_amd import chameleon as ch, client
 
 ch.CHAMELEON_Init(1, 1)
 N, B = int(sys.argv[1]), int(sys.argv[2])
-for dev in (False, True):
-    client.run_cholesky_dag(min(N, 4 * B), B, device_results=dev)  # warm
+for dev, bat in ((False, False), (True, False), (True, True)):
+    client.run_cholesky_dag(min(N, 4 * B), B, device_results=dev, batched=bat)  # warm
     t = time.perf_counter()
-    r = client.run_cholesky_dag(N, B, device_results=dev)
+    r = client.run_cholesky_dag(N, B, device_results=dev, batched=bat)
     dt = time.perf_counter() - t
     n = sum(r.task_counts.values())
-    print(f"device_results={dev}: N={N} B={B} {n} tasks, DAG {r.seconds:.3f} s = {r.seconds / n * 1e3:.3f} ms/task "
+    print(f"device_results={dev} batched={bat}: N={N} B={B} {n} tasks, DAG {r.seconds:.3f} s = {r.seconds / n * 1e3:.3f} ms/task "
           f"({N**3 / 3 / r.seconds / 1e12:.3f} TFLOP/s), whole call {dt:.3f} s", flush=True)
 pr = cProfile.Profile()
 pr.enable()

@@ -218,3 +218,36 @@ def test_c_driver_builds_as_c99_and_fails_loudly_without_a_gpu():
         args = "1 1 256 128 128 128 16384 256 256 0 0 256 256 1 1 42".split()
         r = subprocess.run([exe] + args, capture_output=True, text=True)
         assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_batched_client_is_the_same_dag_with_three_submissions_per_wave():
+    """the non-blocking client.  Same tasks, payloads and results; 3 submit_tasks
+    calls per wave instead of one per task."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from oracle_engine import OracleTileBackend
+
+    from dense_linear_app_amd import armonik as ak, client
+    from dense_linear_app_amd.worker import DagCholeskyWorker
+
+    calls = {"n": 0}
+    orig = ak.TasksClient.submit_tasks
+
+    def counting(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+
+    ak.TasksClient.submit_tasks = counting
+    try:
+        w = DagCholeskyWorker(backend=OracleTileBackend())
+        serial = client.run_cholesky_dag(96, 16, worker=w)
+        n_serial = calls["n"]
+        calls["n"] = 0
+        batched = client.run_cholesky_dag(96, 16, worker=w, batched=True)
+        n_batched = calls["n"]
+    finally:
+        ak.TasksClient.submit_tasks = orig
+    assert serial.task_counts == batched.task_counts == {"POTRF": 6, "TRSM": 15, "SYRK": 15, "GEMM": 20}
+    assert n_serial == 56 and n_batched == 3 * 6 - 2  # the last wave has no TRSM and no updates
+    assert np.array_equal(serial.lower_factor(), batched.lower_factor())
