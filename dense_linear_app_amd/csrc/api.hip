@@ -765,7 +765,7 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
 
 // ---------------------------------------------------------------- V6 validation block
 static int resident_whole(const char *what, const chol_desc *d) {
-  static char buf[160];
+  char buf[160];
   const char *why = nullptr;
   if (!d) why = "NULL descriptor";
   else if (!d->on_device) why = "descriptor must be device-resident";

@@ -748,36 +748,17 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   __syncthreads();
 }
 
-// Wait until the LDS counter at byte address `lds_addr` reaches `target` (phase A of the
-// diagonal-block kernel: columns published by wave 0).  One opaque instruction sequence on
-// purpose: written as a C loop, sixteen unrolled copies of it gave the register allocator a
-// control-flow graph on which the kernel needed 400 VGPRs instead of 256.  Bounded (the producer
-// needs ~1 us per column even beside a running update; the bound is ~1 ms): a logic error shows up
-// as a wrong result in the tests, never as a hung GPU.
-__device__ __forceinline__ void wait_published(unsigned lds_addr, int target) {
-  int v, n = 0x3fff;
-  asm volatile(
-      "1:\n\t"
-      "ds_read_b32 %0, %2\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
-      "s_cbranch_vccz 2f\n\t"
-      "s_sub_u32 %1, %1, 1\n\t"
-      "s_cmp_eq_u32 %1, 0\n\t"
-      "s_cbranch_scc1 2f\n\t"
-      "s_sleep 1\n\t"
-      "s_branch 1b\n\t"
-      "2:"
-      : "=&v"(v), "+s"(n)
-      : "v"(lds_addr), "s"(target)
-      : "vcc", "scc", "memory");
-}
-
 // Consumer side of phase A: fetch column `jj` of the 16x16 factor (16 values), 1/pivot and the
 // publication counter in ONE LDS round trip and retry until the counter says the column was
 // complete when the reads were issued (DS operations execute in order, the counter is read first
-// and written last, so a satisfied counter vouches for the data behind it).  Opaque and bounded for
-// the same reasons as wait_published.
+// and written last, so a satisfied counter vouches for the data behind it).  One opaque instruction
+// sequence on purpose: written as a C loop, sixteen unrolled copies of it gave the register allocator
+// a control-flow graph on which the kernel needed 400 VGPRs instead of 256.  Bounded (the producer
+// needs ~1 us per column even beside a running update; the bound is ~1 ms): on giving up it stores
+// a value other than 0 / 1 into DiagLds::failed, which the kernel turns into info = INT_MAX after
+// the panel's barrier -- a logic error shows up as a loud failure, never as a hung GPU or a
+// silently wrong factor.  (Returning a flag instead and testing it in C++ put the kernel back over
+// the register limit.)
 template <typename T>
 struct ColFetch;
 template <>
@@ -786,7 +767,8 @@ struct ColFetch<double> {
   v2_t c[8];
   double rinv;
   __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
-  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target) {
+  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
+                                        unsigned failed_addr) {
     int v, n = 0x3fff;
     asm volatile(
         "1:\n\t"
@@ -805,13 +787,15 @@ struct ColFetch<double> {
         "s_cbranch_vccz 2f\n\t"
         "s_sub_u32 %10, %10, 1\n\t"
         "s_cmp_eq_u32 %10, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 3f\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
+        "3:\n\t"
+        "ds_write_b32 %15, %15\n\t"
         "2:"
         : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
           "=&v"(c[7]), "=&v"(rinv), "+s"(n)
-        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target)
+        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target), "v"(failed_addr)
         : "vcc", "scc", "memory");
   }
 };
@@ -821,7 +805,8 @@ struct ColFetch<float> {
   v2_t c[8];
   float rinv;
   __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
-  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target) {
+  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
+                                        unsigned failed_addr) {
     int v, n = 0x3fff;
     asm volatile(
         "1:\n\t"
@@ -840,13 +825,15 @@ struct ColFetch<float> {
         "s_cbranch_vccz 2f\n\t"
         "s_sub_u32 %10, %10, 1\n\t"
         "s_cmp_eq_u32 %10, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 3f\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
+        "3:\n\t"
+        "ds_write_b32 %15, %15\n\t"
         "2:"
         : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
           "=&v"(c[7]), "=&v"(rinv), "+s"(n)
-        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target)
+        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target), "v"(failed_addr)
         : "vcc", "scc", "memory");
   }
 };
@@ -960,6 +947,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
           const bool active = rows ? (j0 + NB + 64 * (w - 1) < n) : true;
           if (active) {
             const unsigned flag_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&L.colready;
+            const unsigned failed_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&L.failed;
             T a[NB];
             const int rr = rowok ? myrow : n - 1;
             T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
@@ -969,7 +957,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) {
               ColFetch<T> cf;
-              cf.fetch(flag_lds, col_lds + jj * NB * (unsigned)sizeof(T), rinv_lds + jj * (unsigned)sizeof(T), fbase + jj + 1);
+              cf.fetch(flag_lds, col_lds + jj * NB * (unsigned)sizeof(T), rinv_lds + jj * (unsigned)sizeof(T),
+                       fbase + jj + 1, failed_lds);
               a[jj] *= cf.rinv;
 #pragma unroll
               for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * cf.at(c);
@@ -987,7 +976,10 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
         }
       }
       __syncthreads();
-      if (failed) return;
+      if (failed) {
+        if (failed != 1 && t == 0) atomicCAS(info, 0, 0x7fffffff);  // a consumer gave up waiting (ColFetch)
+        return;
+      }
       tA += PH_NOW() - tl;
       tl = PH_NOW();
       // ---- phase B: S(r,c) -= X(r,p) X(c,p)^T for 16x16 blocks p < c <= r

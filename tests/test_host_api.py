@@ -251,3 +251,31 @@ def test_batched_client_is_the_same_dag_with_three_submissions_per_wave():
     assert serial.task_counts == batched.task_counts == {"POTRF": 6, "TRSM": 15, "SYRK": 15, "GEMM": 20}
     assert n_serial == 56 and n_batched == 3 * 6 - 2  # the last wave has no TRSM and no updates
     assert np.array_equal(serial.lower_factor(), batched.lower_factor())
+
+
+def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
+    """The schedule relies on co-residency: two trailing-update workgroups per
+    CU, and every kernel of the panel chain able to start on a CU as soon as ONE of them has left
+    it.  Read from the kernel descriptors of the built code object: allocated VGPRs per lane
+    (512 per SIMD lane, one wave of each workgroup per SIMD) and LDS bytes (160 KiB per CU).
+    The diagonal-block kernel once drifted to 406 VGPRs and silently waited for whole CUs to drain."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import codeobj
+    from dense_linear_app_amd._lib import LIB_PATH
+
+    res = codeobj.kernel_resources(LIB_PATH)
+
+    def find(*parts):
+        hits = [v for k, v in res.items() if all(p in k for p in parts)]
+        assert len(hits) == 1, (parts, [k for k in res if parts[0] in k])
+        return hits[0]
+
+    for t in ("d", "f"):
+        upd = find("k_trail_updateI%sLb1E" % t)
+        assert 2 * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
+        for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE"):
+            g = find(guest % t)
+            assert g["vgprs"] + upd["vgprs"] <= 512, (guest % t, g, upd)
+            assert g["lds"] + upd["lds"] <= 160 * 1024, (guest % t, g, upd)
