@@ -6,19 +6,20 @@
 //
 // Common structure ("NT core"): one 256-thread workgroup (4 waves, 2 x 2) owns a
 // 128 x 128 block of C and computes  acc = A(128 x K) * B(128 x K)^T  with both
-// operands column-major (rows contiguous), staged through LDS in K-slices of 16:
-//   - global -> registers: 16-byte loads, one wave instruction = 1 KiB contiguous
-//     (a whole 128-row column of the slice): fully coalesced;
-//   - registers -> LDS image [k][row], row stride 144 elements so the four
-//     16-lane groups of a fragment read land on disjoint bank halves;
-//   - LDS -> MFMA fragments: lane l reads X[k0 + (l >> 4)][r0 + (l & 15)], which is
-//     exactly the 16x16x4 operand layout for both the A and the B operand;
-//   - the operands are passed swapped (B-fragment as MFMA "A"), so each lane's
-//     accumulator holds consecutive ROWS of C in consecutive lanes: the C
-//     read-modify-write is 128-byte contiguous per 16 lanes (col-major C).
-// Double-buffered LDS, one barrier per K-slice; 2 workgroups per CU
-// (<= 256 VGPR, 72 KiB LDS each) hide the C epilogue behind the other
-// workgroup's MFMA stream.
+// operands column-major (rows contiguous), staged through LDS in K-slices of 16.
+// Production form (nt_kloop_paired + nt_epilogue_paired_impl):
+//   - global -> LDS by LDS-DMA (global_load_lds, 16 B per lane): one wave instruction moves a
+//     whole 128-row column of a slice into the [k][128] LDS image, no staging registers;
+//   - LDS -> MFMA fragments by ds_read_b128 with "paired" rows: lane i of a 16-lane group owns
+//     16 B of consecutive rows, so one read feeds 2 (fp64) / 4 (fp32) MFMA tiles; the unpadded
+//     128-element row stride makes the four 16-lane groups of a read cover the 64 banks once;
+//   - the operands are passed swapped (B-fragment as MFMA "A"), so each lane's accumulator holds
+//     consecutive ROWS of C in consecutive lanes: the C read-modify-write is 16 B per lane,
+//     contiguous per 16 lanes (col-major C);
+//   - double-buffered LDS (64 KiB per workgroup), one barrier per K-slice; 2 workgroups per CU
+//     (<= 232 VGPR) hide the C epilogue behind the other workgroup's MFMA stream.
+// nt_kloop (register-staged, row stride 144) is the first version: it carries the operand masks
+// the residual kernel needs and the ablation switches of the diagnostic twin of the update.
 #include "cholmi_internal.h"
 
 namespace cholmi {
