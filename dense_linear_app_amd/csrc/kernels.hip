@@ -22,6 +22,8 @@
 // the residual kernel needs and the ablation switches of the diagnostic twin of the update.
 #include "cholmi_internal.h"
 
+#include <type_traits>
+
 namespace cholmi {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -749,6 +751,77 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   __syncthreads();
 }
 
+// compile-time loop (indices usable as constants inside the body)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Producer side of phase A: the 16 values of a just-published column as one burst of LDS
+// broadcast reads into registers of their own, issued without waiting; wait() before the first use.
+template <typename T>
+struct ColBurst;
+template <>
+struct ColBurst<double> {
+  typedef double v2_t __attribute__((ext_vector_type(2)));
+  v2_t c[8];
+  __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
+  // `anchor` is passed through untouched: whatever uses it afterwards (the critical update of the
+  // next pivot) cannot be scheduled above the burst
+  __device__ __forceinline__ void issue(unsigned col_addr, double &anchor) {
+    asm volatile(
+        "ds_read2_b64 %0, %9 offset1:1\n\t"
+        "ds_read2_b64 %1, %9 offset0:2 offset1:3\n\t"
+        "ds_read2_b64 %2, %9 offset0:4 offset1:5\n\t"
+        "ds_read2_b64 %3, %9 offset0:6 offset1:7\n\t"
+        "ds_read2_b64 %4, %9 offset0:8 offset1:9\n\t"
+        "ds_read2_b64 %5, %9 offset0:10 offset1:11\n\t"
+        "ds_read2_b64 %6, %9 offset0:12 offset1:13\n\t"
+        "ds_read2_b64 %7, %9 offset0:14 offset1:15"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]),
+          "+v"(anchor)
+        : "v"(col_addr)
+        : "memory");
+  }
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
+                 "+v"(c[6]), "+v"(c[7]) : : "memory");
+  }
+  // same, and not before `anchor` (a value of the pivot chain) has been produced
+  __device__ __forceinline__ void wait(double &anchor) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
+                 "+v"(c[6]), "+v"(c[7]), "+v"(anchor) : : "memory");
+  }
+};
+template <>
+struct ColBurst<float> {
+  typedef float v2_t __attribute__((ext_vector_type(2)));
+  v2_t c[8];
+  __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
+  __device__ __forceinline__ void issue(unsigned col_addr, float &anchor) {
+    asm volatile(
+        "ds_read2_b32 %0, %9 offset1:1\n\t"
+        "ds_read2_b32 %1, %9 offset0:2 offset1:3\n\t"
+        "ds_read2_b32 %2, %9 offset0:4 offset1:5\n\t"
+        "ds_read2_b32 %3, %9 offset0:6 offset1:7\n\t"
+        "ds_read2_b32 %4, %9 offset0:8 offset1:9\n\t"
+        "ds_read2_b32 %5, %9 offset0:10 offset1:11\n\t"
+        "ds_read2_b32 %6, %9 offset0:12 offset1:13\n\t"
+        "ds_read2_b32 %7, %9 offset0:14 offset1:15"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]),
+          "+v"(anchor)
+        : "v"(col_addr)
+        : "memory");
+  }
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
+                 "+v"(c[6]), "+v"(c[7]) : : "memory");
+  }
+};
+
 // Consumer side of phase A: fetch column `jj` of the 16x16 factor (16 values), 1/pivot and the
 // publication counter in ONE LDS round trip and retry until the counter says the column was
 // complete when the reads were issued (DS operations execute in order, the counter is read first
@@ -910,12 +983,61 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #pragma unroll
           for (int jj = 0; jj < NB; ++jj) dd[jj] = Dp[jj * DB_LD];
           int bad = 0;
-#pragma unroll
-          for (int jj = 0; jj < NB; ++jj) {
+          // Software-pipelined by hand.  Column jj-1's updates of the columns c >= jj+1 have a
+          // whole iteration of slack (only its update of column jj is on the way to the next
+          // pivot, and that one is done straight from the lane by v_readlane): their multipliers
+          // are fetched from the column just published -- one burst of LDS broadcast reads into
+          // their own registers, not waited for -- and applied a few at a time BETWEEN the
+          // dependent steps of the next column's pivot chain, where an in-order wave would
+          // otherwise idle.  (Left to the compiler under the 256-VGPR cap, the fetch degenerated
+          // into six serial read-wait-use round trips per column ahead of the next pivot.)
+          ColBurst<T> prev;
+#define DEFER(k)                                                     \
+  do {                                                               \
+    constexpr int c_ = jj + 1 + (k);                                 \
+    if constexpr (jj >= 1 && c_ < NB) dd[c_] -= dd[jj - 1] * prev.at(c_); \
+  } while (0)
+          static_for<0, NB>([&](auto JJ) {
+            constexpr int jj = decltype(JJ)::value;
             const T d = rlane(dd[jj], jj);
             if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
             T sq, rinv;
-            sqrt_rsqrt(d, sq, rinv);
+            if constexpr (sizeof(T) == 8) {
+              // PIN ties a chain value and the deferred results just produced into one (empty) asm:
+              // what follows in the chain cannot be scheduled above them, so the interleaving below
+              // is the issue order (the scheduler otherwise packs the dependent chain first and the
+              // fourteen independent FMAs behind it, which an in-order wave then executes in series)
+#define PIN2(x, k0, k1)                                                                                  \
+  do {                                                                                                   \
+    constexpr int a_ = jj + 1 + (k0), b_ = jj + 1 + (k1);                                                \
+    if constexpr (jj >= 1 && b_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]), "+v"(dd[b_]));           \
+    else if constexpr (jj >= 1 && a_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]));                    \
+  } while (0)
+              double r = __builtin_amdgcn_rsq((double)d);
+              double g = d * r, h = 0.5 * r;
+              double e = __builtin_fma(-h, g, 0.5);
+              if constexpr (jj >= 1) prev.wait(e);
+              DEFER(0); DEFER(1); PIN2(e, 0, 1);
+              g = __builtin_fma(g, e, g);
+              h = __builtin_fma(h, e, h);
+              DEFER(2); DEFER(3); PIN2(h, 2, 3);
+              e = __builtin_fma(-h, g, 0.5);
+              DEFER(4); DEFER(5); PIN2(e, 4, 5);
+              g = __builtin_fma(g, e, g);
+              h = __builtin_fma(h, e, h);
+              DEFER(6); DEFER(7); PIN2(h, 6, 7);
+              const double cc = __builtin_fma(-g, g, (double)d);
+              rinv = (T)(h + h);
+              DEFER(8); DEFER(9); PIN2(rinv, 8, 9);
+              sq = (T)__builtin_fma(cc, h, g);
+              DEFER(10); DEFER(11); DEFER(12); DEFER(13);
+#undef PIN2
+            } else {
+              if constexpr (jj >= 1) prev.wait();
+              DEFER(0); DEFER(1); DEFER(2); DEFER(3); DEFER(4); DEFER(5); DEFER(6);
+              DEFER(7); DEFER(8); DEFER(9); DEFER(10); DEFER(11); DEFER(12); DEFER(13);
+              sqrt_rsqrt(d, sq, rinv);
+            }
             dd[jj] = (lo_ == jj) ? sq : dd[jj] * rinv;
             // every lane stores (lanes 16-63 hold copies of rows 0-15; 1/pivot and the counter are
             // wave-uniform): same address, same value -- no exec-mask region on the critical chain
@@ -925,12 +1047,11 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             asm volatile("" ::: "memory");
             __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
-            // L(c, jj): the next pivot's column straight from the lane_ (critical chain), the others
-            // as LDS broadcasts of the column just published (off the chain, no SGPR traffic)
-#pragma unroll
-            for (int c = jj + 1; c < NB; ++c)
-              dd[c] -= dd[jj] * ((c == jj + 1) ? rlane(dd[jj], c) : Lc[jj * NB + c]);
-          }
+            if constexpr (jj + 2 < NB) prev.issue((unsigned)(size_t)Lc + jj * NB * (unsigned)sizeof(T), dd[jj]);
+            // the next pivot's column: L(jj+1, jj) straight from the lane (critical chain)
+            if constexpr (jj + 1 < NB) dd[jj + 1] -= dd[jj] * rlane(dd[jj], jj + 1);
+          });
+#undef DEFER
           if (bad) {
             if (lane_ == 0) {
               atomicCAS(info, 0, info_base + j0 + bad);
