@@ -939,16 +939,25 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   // (no per-element index arithmetic), 16 independent accesses in flight, rows of consecutive
   // threads contiguous in global memory.
   const int gi = t & (n - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
-#pragma unroll 1
-  for (int c = gc0; c < gc0 + 4; ++c) {
-    if (gr < c) continue;
-    T v[16];
-    const T *src = A + gi + (size_t)(NB * c) * ld;
+  {
+    // all four block columns of the row at once: up to 64 independent loads in flight per thread
+    // (the kernel starts cold, behind the launch that produced the block: latency, not bandwidth)
+    T v[4][16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (gr > c || (gi & 15) >= u) ? src[(size_t)u * ld] : T(0);
-    T *dst = S + db_off(gr, c) + (gi & 15);
+    for (int q = 0; q < 4; ++q) {
+      const int c = gc0 + q;
+      const T *src = A + gi + (size_t)(NB * c) * ld;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[u];
+      for (int u = 0; u < 16; ++u) v[q][u] = (gr > c || (gr == c && (gi & 15) >= u)) ? src[(size_t)u * ld] : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = gc0 + q;
+      if (gr < c) continue;
+      T *dst = S + db_off(gr, c) + (gi & 15);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
+    }
   }
   if (t == 0) {
     failed = 0;
