@@ -7,6 +7,8 @@ from dense_linear_app_amd import chameleon as ch
 ch.CHAMELEON_Init(1, 1)
 cfgs = [(4096, 512, "f64", 120), (8192, 1024, "f64", 60), (6144, 256, "f64", 40), (5000, 448, "f64", 30),
         (8192, 512, "f32", 40), (16384, 1024, "f64", 25), (12288, 128, "f64", 10)]
+if os.environ.get("STRESS_BIG") == "1":  # the compute-bound regime: panel kernels beside a running update
+    cfgs += [(32768, 1024, "f64", 12), (32768, 512, "f64", 8), (65536, 1024, "f64", 3), (65536, 1024, "f32", 4)]
 worst = {}
 t0 = time.time()
 for N, B, dt, reps in cfgs:
