@@ -210,8 +210,9 @@ def main() -> int:
             line["roofline"] = {
                 "bound": "mfma", "kernel": "k_trail_update", "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": (traffic or {}).get("hbm_bytes_per_launch") if traffic and
-                traffic.get("N") == a.N and traffic.get("tile") == a.tile else None,
+                # PMC pass = one factorisation: bytes per launch at THIS run's launch count
+                "traffic": (traffic["hbm_bytes_per_launch"] * traffic["launches"] / (r["upd_launches"] / a.steps))
+                if traffic and traffic.get("N") == a.N and traffic.get("tile") == a.tile else None,
                 "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
                 "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
             }

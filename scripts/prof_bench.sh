@@ -34,6 +34,7 @@ n = max(1, res["FETCH_SIZE"][1])
 j = {"N": 65536, "tile": 1024, "kernel": "k_trail_update", "launches": n,
      "fetch_bytes_per_launch_corrected_x2": fetch_b / n, "write_bytes_per_launch": write_b / max(1, res["WRITE_SIZE"][1]),
      "hbm_bytes_per_launch": fetch_b / n + write_b / max(1, res["WRITE_SIZE"][1]),
+     "hbm_bytes_per_factorisation": fetch_b + write_b,
      "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one factorisation; FETCH_SIZE doubled per the gfx950 correction"}
 json.dump(j, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
 print(json.dumps(j))
