@@ -250,7 +250,11 @@ int potrf_full_device(chol_desc *d, void *base) {
       if (yield || split_always) {
         // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
         // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
-        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
+        if (cholmi::g_intile_small)
+          launch_diag_syrk<T>(g.s_main, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
+                              M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
+        else
+          launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
         HIPCHECK(hipEventRecord(ev_u1, g.s_main));
         launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
         HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
@@ -507,6 +511,7 @@ int chol_init(int ncpu, int ngpu) {
   HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_trsm, hipStreamNonBlocking, hi));
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
+  if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
@@ -1234,6 +1239,16 @@ int chol_wave_update_diag(chol_desc_t *d, int k, int j, const void *const *panel
   if (!d || !panel_base || !panel_first) return fail(-1, "wave_update_diag: NULL");
   if (j <= k || j >= d->nt) return fail(-3, "wave_update_diag: j out of range");
   if (!owns_tile(d, j, j)) return fail(-3, "wave_update_diag: this process does not own tile (j,j)");
+  if (cholmi::g_intile_small) {
+    const int pr = j % d->p;
+    const size_t aoff = (size_t)(j / d->p - panel_first[pr]) * d->bsizi, coff = ((size_t)(j / d->p) + (size_t)(j / d->q) * d->lmt) * d->bsizi;
+    if (d->dtype == CHOL_REAL_DOUBLE)
+      launch_diag_syrk<double>((hipStream_t)stream, (double *)d->mat + coff, (const double *)panel_base[pr] + aoff, d->mbi);
+    else
+      launch_diag_syrk<float>((hipStream_t)stream, (float *)d->mat + coff, (const float *)panel_base[pr] + aoff, d->mbi);
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   ColRange r;
   r.off = 0;
   r.na = 0;

@@ -32,6 +32,7 @@ struct LocalMat {
 
 extern int g_ablate;
 extern int g_variant;
+extern int g_intile_small;
 extern unsigned long long *g_dbg;
 extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;
@@ -51,6 +52,10 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
 // at the first non-positive pivot (first writer wins).
 template <typename T>
 void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base);
+
+// C (mb x mb tile, lower part) -= A A^T, A one tile: 64 x 64 blocks, one workgroup each (critical chain)
+template <typename T>
+void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 
 // POTRF(tile) on stream sp with the TRSM of `ntiles` contiguous tiles pipelined behind it on
 // stream st (ev: mb/MACRO events).  The caller joins both streams.

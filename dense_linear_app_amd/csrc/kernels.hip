@@ -602,6 +602,155 @@ __global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int n
   guest.leave();
 }
 
+// ------------------------------------------------------------------------------
+// The in-tile steps of the tile POTRF in small-block form.  They are K = 128 products of a
+// handful of blocks on the critical chain (diagonal block -> solve -> update -> next diagonal
+// block); in the 128 x 128 NT core one such block is 8 K-slices of a DMA pipeline that never
+// fills: 19-22 us, 3x its MFMA time.  Here a workgroup takes a quarter of the work (solve: a
+// 32-row slab of the block row, all 128 columns, so that it can run in place; update: a 64 x 64
+// block), K in four phases of 32 staged global -> registers -> LDS with the next phase's loads
+// in flight under the current phase's MFMAs, one wave = 32 x 32 of the output = 2 x 2 MFMA
+// tiles.  LDS image [k][rows + 16]: the row stride puts the four 16-lane k-groups of a fragment
+// read on alternating bank halves (conflict-free for 8-byte reads).
+// ------------------------------------------------------------------------------
+constexpr int SK = 32;
+template <typename T, int ROWS>
+struct SmallImg {
+  T v[SK][ROWS + 16];
+};
+template <typename T, int ROWS>
+__device__ __forceinline__ void small_gload(const T *__restrict__ P, int ld, int k0, T (&r)[ROWS * SK / 256]) {
+#pragma unroll
+  for (int q = 0; q < ROWS * SK / 256; ++q) {
+    const int e = threadIdx.x + 256 * q;
+    r[q] = P[(e % ROWS) + (long)(k0 + e / ROWS) * ld];
+  }
+}
+template <typename T, int ROWS>
+__device__ __forceinline__ void small_lstore(SmallImg<T, ROWS> &img, const T (&r)[ROWS * SK / 256]) {
+#pragma unroll
+  for (int q = 0; q < ROWS * SK / 256; ++q) {
+    const int e = threadIdx.x + 256 * q;
+    img.v[e / ROWS][e % ROWS] = r[q];
+  }
+}
+// acc[a][b] += A(i0 + 16a .. , k) B(j0 + 16b .., k)^T over the SK k's of the images; operands
+// swapped so that accumulator register r of lane l is (row i0 + 16a + (l & 15), col j0 + 16b + drow(l, r))
+template <typename T, int RA, int RB>
+__device__ __forceinline__ void small_mma(const SmallImg<T, RA> &ia, const SmallImg<T, RB> &ib, int i0, int j0,
+                                          typename Tr<T>::acc_t (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < SK / 4; ++ks) {
+    const int k = 4 * ks + kq;
+    T af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[a] = ia.v[k][i0 + 16 * a + lo];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[b] = ib.v[k][j0 + 16 * b + lo];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = Tr<T>::mfma(bf[b], af[a], acc[a][b]);
+  }
+}
+
+// X[slab, 0..127] = alpha * A[slab, 0..127] * Winv_s^T, in place: one workgroup per 32-row slab of
+// the block rows s+1.. of the tile (it reads only its own rows, all of them before it writes).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_intile_solve_small(T *tile, int mb, int s, const T *__restrict__ winv,
+                                                               T alpha, int *ytab) {
+  __shared__ SmallImg<T, 32> ia;
+  __shared__ SmallImg<T, MACRO> ib;
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
+  T *Ap = tile + (long)(s + 1) * MACRO + 32 * blockIdx.x + (long)s * MACRO * mb;
+  const T *Bp = winv + (long)s * MACRO * MACRO;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15;
+  T ra[32 * SK / 256], rb[MACRO * SK / 256];
+  typename Tr<T>::acc_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+  small_gload<T, 32>(Ap, mb, 0, ra);
+  small_gload<T, MACRO>(Bp, MACRO, 0, rb);
+  for (int ph = 0; ph < MACRO / SK; ++ph) {
+    small_lstore<T, 32>(ia, ra);
+    small_lstore<T, MACRO>(ib, rb);
+    __syncthreads();
+    if (ph + 1 < MACRO / SK) {
+      small_gload<T, 32>(Ap, mb, (ph + 1) * SK, ra);
+      small_gload<T, MACRO>(Bp, MACRO, (ph + 1) * SK, rb);
+    }
+    small_mma<T, 32, MACRO>(ia, ib, 0, 32 * w, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Ap[16 * a + lo + (long)(32 * w + 16 * b + Tr<T>::drow(lane, r)) * mb] = alpha * acc[a][b][r];
+  guest.leave();
+}
+
+// C(r64, c64) -= A(r64, :) B(c64, :)^T over K columns, for the 64 x 64 blocks on or below the
+// diagonal of a square C; diagonal blocks write i >= j only.  Two uses, both on the critical chain:
+// the in-tile trailing update (C = the trailing part of the tile, A = B = block column s, K = 128)
+// and the single SYRK on the next diagonal tile, C(k+1,k+1) -= L(k+1,k) L(k+1,k)^T (K = mb), which
+// releases POTRF(k+1).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T *__restrict__ A,
+                                                        const T *__restrict__ B, long ldab, int K, int *ytab) {
+  __shared__ SmallImg<T, 64> ia, ib;
+  const int r64 = blockIdx.x, c64 = blockIdx.y;
+  if (c64 > r64) return;
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
+  const T *Ap = A + 64 * r64;
+  const T *Bp = B + 64 * c64;
+  T *Cp = C + 64 * r64 + 64 * c64 * ldc;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15;
+  const int i0 = 32 * (w & 1), j0 = 32 * (w >> 1);
+  T ra[64 * SK / 256], rb[64 * SK / 256];
+  typename Tr<T>::acc_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+  small_gload<T, 64>(Ap, (int)ldab, 0, ra);
+  small_gload<T, 64>(Bp, (int)ldab, 0, rb);
+  const int nph = K / SK;
+  for (int ph = 0; ph < nph; ++ph) {
+    small_lstore<T, 64>(ia, ra);
+    small_lstore<T, 64>(ib, rb);
+    __syncthreads();
+    if (ph + 1 < nph) {
+      small_gload<T, 64>(Ap, (int)ldab, (ph + 1) * SK, ra);
+      small_gload<T, 64>(Bp, (int)ldab, (ph + 1) * SK, rb);
+    }
+    small_mma<T, 64, 64>(ia, ib, i0, j0, acc);
+    __syncthreads();
+  }
+  const bool dg = (r64 == c64);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * a + lo, j = j0 + 16 * b + Tr<T>::drow(lane, r);
+        if (!dg || i >= j) Cp[i + (long)j * ldc] -= acc[a][b][r];
+      }
+  guest.leave();
+}
+
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A,
@@ -1441,6 +1590,7 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU hand-over), may be null
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
+int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
 template <typename T>
@@ -1464,6 +1614,12 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
                                                  yield ? g_ytab : nullptr);
 }
 
+// C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
+template <typename T>
+void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb) {
+  k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, s>>>(C, mb, A, A, mb, mb, g_ytab);
+}
+
 template <typename T>
 void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base) {
   const int nbm = mb / MACRO;
@@ -1473,8 +1629,17 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
     const int nr = nbm - 1 - st;
     if (nr > 0) {
       // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
-      k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1), g_ytab);
-      k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st, g_ytab);
+      if (g_intile_small) {
+        k_intile_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, mb, st, winv, T(1), g_ytab);
+        {
+          T *tr = tile + (long)(st + 1) * MACRO * (mb + 1);  // trailing part of the tile
+          const T *xs = tile + (long)(st + 1) * MACRO + (long)st * MACRO * mb;  // block column st below the diagonal
+          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, s>>>(tr, mb, xs, xs, mb, MACRO, g_ytab);
+        }
+      } else {
+        k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1), g_ytab);
+        k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st, g_ytab);
+      }
     }
   }
 }
@@ -1492,7 +1657,12 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
     const int nr = nbm - 1 - s;
     k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
                                        d_info, info_base + s * MACRO, 1, g_dbg, g_ytab);
-    if (nr > 0) k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
+    if (nr > 0) {
+      if (g_intile_small)
+        k_intile_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, mb, s, winv, T(1), g_ytab);
+      else
+        k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
+    }
     if (ntiles > 0) {
       (void)hipEventRecord(ev[s], sp);
       (void)hipStreamWaitEvent(st, ev[s], 0);
@@ -1500,7 +1670,16 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       if (nr > 0)
         k_panel_update<T><<<ntiles * nbm * nr, 256, 0, st>>>(tiles, bsiz, mb, nbm, s, lkk, T(1), g_ytab);
     }
-    if (nr > 0) k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
+    if (nr > 0) {
+      if (g_intile_small)
+        {
+        T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
+        const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
+        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab);
+      }
+      else
+        k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
+    }
   }
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
@@ -1601,6 +1780,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int, int,  \
                                        int, const PanelRef &, bool);                                \
   template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int);                       \
+  template void launch_diag_syrk<T>(hipStream_t, T *, const T *, int);                               \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
   template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
   template void launch_gemm_nt_tile<T>(hipStream_t, const T *, const T *, T *, int, T, T, bool);    \
