@@ -656,15 +656,18 @@ __device__ __forceinline__ void small_mma(const SmallImg<T, RA> &ia, const Small
 }
 
 // X[slab, 0..127] = alpha * A[slab, 0..127] * Winv_s^T, in place: one workgroup per 32-row slab of
-// the block rows s+1.. of the tile (it reads only its own rows, all of them before it writes).
+// the block rows r0.. of each of the tiles at tiles + q*bsiz (it reads only its own rows, all of
+// them before it writes).  In-tile step: one tile, r0 = s+1; panel TRSM step: all panel tiles, r0 = 0.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_intile_solve_small(T *tile, int mb, int s, const T *__restrict__ winv,
-                                                               T alpha, int *ytab) {
+__global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int mb, int nbm, int r0, int s,
+                                                        const T *__restrict__ winv, T alpha, int *ytab) {
   __shared__ SmallImg<T, 32> ia;
   __shared__ SmallImg<T, MACRO> ib;
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);
-  T *Ap = tile + (long)(s + 1) * MACRO + 32 * blockIdx.x + (long)s * MACRO * mb;
+  const int per_tile = 4 * (nbm - r0);
+  const int tix = blockIdx.x / per_tile, slab = blockIdx.x % per_tile;
+  T *Ap = tiles + (long)tix * bsiz + (long)r0 * MACRO + 32 * slab + (long)s * MACRO * mb;
   const T *Bp = winv + (long)s * MACRO * MACRO;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15;
   T ra[32 * SK / 256], rb[MACRO * SK / 256];
@@ -699,16 +702,21 @@ __global__ __launch_bounds__(256, 2) void k_intile_solve_small(T *tile, int mb, 
 }
 
 // C(r64, c64) -= A(r64, :) B(c64, :)^T over K columns, for the 64 x 64 blocks on or below the
-// diagonal of a square C; diagonal blocks write i >= j only.  Two uses, both on the critical chain:
+// diagonal of a square C (diagonal blocks write i >= j only), or, full != 0, for every block of a
+// rectangular C.  Uses, all on the critical chain: the panel TRSM step A[:, c] -= X[:, s] L(c, s)^T
+// (full; blockIdx.z = panel tile),
 // the in-tile trailing update (C = the trailing part of the tile, A = B = block column s, K = 128)
 // and the single SYRK on the next diagonal tile, C(k+1,k+1) -= L(k+1,k) L(k+1,k)^T (K = mb), which
 // releases POTRF(k+1).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T *__restrict__ A,
-                                                        const T *__restrict__ B, long ldab, int K, int *ytab) {
+                                                        const T *__restrict__ B, long ldab, int K, int *ytab,
+                                                        int full, long zc, long za) {
   __shared__ SmallImg<T, 64> ia, ib;
   const int r64 = blockIdx.x, c64 = blockIdx.y;
-  if (c64 > r64) return;
+  if (!full && c64 > r64) return;
+  C += blockIdx.z * zc;  // (panel TRSM step: one z per panel tile, B is the diagonal tile for all)
+  A += blockIdx.z * za;
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);
   const T *Ap = A + 64 * r64;
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
     small_mma<T, 64, 64>(ia, ib, i0, j0, acc);
     __syncthreads();
   }
-  const bool dg = (r64 == c64);
+  const bool dg = !full && (r64 == c64);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1591,6 +1599,7 @@ int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU h
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
+int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
 template <typename T>
@@ -1614,10 +1623,32 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
                                                  yield ? g_ytab : nullptr);
 }
 
+// One 128-column step of the panel TRSM over `ntiles` tiles: X[:, st] = A[:, st] Winv_st^T, then
+// A[:, c] -= X[:, st] L(c, st)^T for the block columns c > st.  Few tiles (the late, chain-bound
+// waves): small-block kernels, latency; many tiles: the 128 x 128 NT core, throughput.
+template <typename T>
+void trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb, int st,
+               T alpha) {
+  const int nbm = mb / MACRO, nc = nbm - 1 - st;
+  if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
+    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab);
+    if (nc > 0)
+      k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
+          tiles + (long)(st + 1) * MACRO * mb, mb, tiles + (long)st * MACRO * mb,
+          lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz);
+    return;
+  }
+  // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
+  // first update of blocks > 0
+  k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab);
+  if (nc > 0)
+    k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab);
+}
+
 // C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
 template <typename T>
 void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb) {
-  k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, s>>>(C, mb, A, A, mb, mb, g_ytab);
+  k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, s>>>(C, mb, A, A, mb, mb, g_ytab, 0, 0, 0);
 }
 
 template <typename T>
@@ -1630,11 +1661,11 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
     if (nr > 0) {
       // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
       if (g_intile_small) {
-        k_intile_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, mb, st, winv, T(1), g_ytab);
+        k_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, 0, mb, nbm, st + 1, st, winv, T(1), g_ytab);
         {
           T *tr = tile + (long)(st + 1) * MACRO * (mb + 1);  // trailing part of the tile
           const T *xs = tile + (long)(st + 1) * MACRO + (long)st * MACRO * mb;  // block column st below the diagonal
-          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, s>>>(tr, mb, xs, xs, mb, MACRO, g_ytab);
+          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, s>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
         }
       } else {
         k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1), g_ytab);
@@ -1659,23 +1690,21 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                        d_info, info_base + s * MACRO, 1, g_dbg, g_ytab);
     if (nr > 0) {
       if (g_intile_small)
-        k_intile_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, mb, s, winv, T(1), g_ytab);
+        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab);
       else
         k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
     }
     if (ntiles > 0) {
       (void)hipEventRecord(ev[s], sp);
       (void)hipStreamWaitEvent(st, ev[s], 0);
-      k_panel_solve<T><<<ntiles * nbm, 256, 0, st>>>(tiles, bsiz, mb, nbm, 0, s, winv, T(1), g_ytab);
-      if (nr > 0)
-        k_panel_update<T><<<ntiles * nbm * nr, 256, 0, st>>>(tiles, bsiz, mb, nbm, s, lkk, T(1), g_ytab);
+      trsm_step<T>(st, tiles, bsiz, ntiles, lkk, winv, mb, s, T(1));
     }
     if (nr > 0) {
       if (g_intile_small)
         {
         T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
         const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
-        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab);
+        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
       }
       else
         k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
@@ -1700,18 +1729,9 @@ void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
                        int mb, T alpha) {
   if (ntiles <= 0) return;
   const int nbm = mb / MACRO;
-  for (int st = 0; st < nbm; ++st) {
-    // alpha is applied once to every column block: in the solve of block 0 and as
-    // the beta of the first update of blocks > 0
-    // the TRSM of the next panel outranks the trailing update whenever the update yields at
-    // all (the walker enables that only while the panel chain is the critical path)
-    k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv,
-                                                  st == 0 ? alpha : T(1), g_ytab);
-    const int nc = nbm - 1 - st;
-    if (nc > 0)
-      k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk,
-                                                          st == 0 ? alpha : T(1), g_ytab);
-  }
+  // the TRSM of the next panel outranks the trailing update whenever the update yields at all (the
+  // walker enables that only while the panel chain is the critical path)
+  for (int st = 0; st < nbm; ++st) trsm_step<T>(s, tiles, bsiz, ntiles, lkk, winv, mb, st, alpha);
 }
 
 template <typename T>
