@@ -272,7 +272,8 @@ int potrf_full_device(chol_desc *d, void *base) {
         ++upd_launches;
       }
       if (g.profiling) HIPCHECK(hipEventRecord(p2, g.s_main));
-      ++upd_launches;
+      // (launches of k_trail_update: the diagonal-tile SYRK of the split form is a k_small_update)
+      if (!((yield || split_always) && cholmi::g_intile_small)) ++upd_launches;
       // algorithmic flops of this wave's update: GEMM 2B^3 per off-diagonal tile,
       // SYRK B^3 per diagonal tile
       const double ntl = (double)(nt - 1 - k);
