@@ -444,14 +444,19 @@ __device__ __forceinline__ const T *panel_tile(const PanelRef &pan, int i, long 
 // diagonal tiles come last: a tile whose blocks leave holes in the middle of a launch splits the
 // 64-workgroup cohort of its XCD into phases for the rest of the launch, which costs the L2 its
 // operand reuse (measured: HBM-side traffic 1.96x -> 1.23x the algorithmic bytes).
-// Per segment, all blocks of a tile (and G consecutive tiles when a tile has fewer than 64 blocks)
-// go to one XCD.  blocks_a = blocks of segment A (a multiple of 8).
+// Per segment the blocks are numbered tile by tile and dealt to the XCDs in UNITS of `unit`
+// consecutive blocks, round-robin.  unit = 64 for a big launch: one unit = the 64 workgroup slots
+// of an XCD = one whole tile at mb = 1024 (or 64 / MT consecutive tiles of a smaller mb), so that
+// the blocks sharing operands run together behind one L2.  A launch of a few tiles (late waves;
+// every launch of a rank when the matrix is spread over 8 GPUs) uses smaller units, down to 8
+// blocks, so that all eight XCDs get the same share instead of whole tiles piling up on some.
+// blocks_a = blocks of segment A (a multiple of 8 units).
 struct BlockMap {
   int2 ij;
   int mi, mj;
 };
 __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, int na, int offb, int nb,
-                                                 int nbm, int blocks_a, BlockMap &out) {
+                                                 int nbm, int blocks_a, int unit, BlockMap &out) {
   int b = blockIdx.x;
   if (na == 0 && nb == 1) {
     // one diagonal tile on its own (the SYRK that releases the next POTRF): nothing to share
@@ -467,11 +472,11 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
     return true;
   }
   if (b < blocks_a) {
-    const int MT = nbm * nbm, G = MT >= 64 ? 1 : 64 / MT;
+    const int MT = nbm * nbm;
     const int x = b & 7, s = b >> 3;
-    const int sg = s / MT, macro = s - sg * MT;
-    const int t = (sg / G) * (8 * G) + x * G + (sg % G);
-    if (t >= na) return false;
+    const int lin = ((s / unit) * 8 + x) * unit + s % unit;
+    if (lin >= na * MT) return false;
+    const int t = lin / MT, macro = lin - t * MT;
     out.ij = list[t];
     out.mi = macro % nbm;
     out.mj = macro / nbm;
@@ -479,14 +484,14 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
     return !(out.ij.x == out.ij.y && out.mi < out.mj);
   }
   b -= blocks_a;
-  const int MTd = nbm * (nbm + 1) / 2, G = MTd >= 64 ? 1 : 64 / MTd;
-  // segment B starts on the XCD after the one that took the last tiles of segment A
-  const int MTa = nbm * nbm, Ga = MTa >= 64 ? 1 : 64 / MTa;
-  const int x = ((b & 7) + 8 - ((na + Ga - 1) / Ga) % 8) & 7, s = b >> 3;
-  const int sg = s / MTd;
-  int macro = s - sg * MTd;
-  const int t = (sg / G) * (8 * G) + x * G + (sg % G);
-  if (t >= nb) return false;
+  const int MTd = nbm * (nbm + 1) / 2;
+  // segment B starts on the XCD after the one that took the last unit of segment A
+  const int ua = (na * nbm * nbm + unit - 1) / unit;
+  const int x = ((b & 7) + 8 - ua % 8) & 7, s = b >> 3;
+  const int lin = ((s / unit) * 8 + x) * unit + s % unit;
+  if (lin >= nb * MTd) return false;
+  const int t = lin / MTd;
+  int macro = lin - t * MTd;
   out.ij = list[offb + t];
   int mj = 0;  // lower triangle, column by column: column mj holds nbm - mj blocks
   while (macro >= nbm - mj) {
@@ -501,10 +506,10 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const int2 *__restrict__ list,
                                                          int na, int offb, int nb, int blocks_a, PanelRef pan,
-                                                         int nbm, int ablate) {
+                                                         int nbm, int unit, int ablate) {
   __shared__ Smem<T> sm;
   BlockMap bm;
-  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, bm)) return;
+  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
   const int2 ij = bm.ij;
   const int mi = bm.mi, mj = bm.mj;
   const bool diag = (ij.x == ij.y);
@@ -521,10 +526,10 @@ __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const 
 template <typename T, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
                                                            int na, int offb, int nb, int blocks_a, PanelRef pan,
-                                                           int nbm, const int *ytab) {
+                                                           int nbm, int unit, const int *ytab) {
   __shared__ SmemP<T> sm;
   BlockMap bm;
-  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, bm)) return;
+  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
   const int2 ij = bm.ij;
   const int mi = bm.mi, mj = bm.mj;
   const bool diag = (ij.x == ij.y);
@@ -1608,18 +1613,20 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   if (na + nb <= 0) return;
   offb -= off;  // the kernels index from d_list + off
   const int nbm = C.mb / MACRO, MT = nbm * nbm, MTd = nbm * (nbm + 1) / 2;
-  const int Ga = MT >= 64 ? 1 : 64 / MT, Gd = MTd >= 64 ? 1 : 64 / MTd;
-  long blocks_a = (long)((na + 8 * Ga - 1) / (8 * Ga)) * 8 * Ga * MT;
-  long blocks_b = (long)((nb + 8 * Gd - 1) / (8 * Gd)) * 8 * Gd * MTd;
+  const long tot_a = (long)na * MT, tot_b = (long)nb * MTd;
+  int unit = 64;  // blocks dealt to an XCD at a time (map_update_block)
+  while (unit > 8 && (tot_a + tot_b) / unit < 64) unit >>= 1;
+  long blocks_a = ((tot_a + unit - 1) / unit + 7) / 8 * 8 * unit;
+  long blocks_b = ((tot_b + unit - 1) / unit + 7) / 8 * 8 * unit;
   if (na == 0 && nb == 1) blocks_a = 0, blocks_b = MTd;  // single diagonal tile: spread, no padding
   const dim3 grid((unsigned)(blocks_a + blocks_b)), blk(256);
   if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
-    k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, g_ablate & 255);
+    k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, g_ablate & 255);
   else if (g_variant == 1)
-    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm,
+    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                   yield ? g_ytab : nullptr);
   else
-    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm,
+    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                  yield ? g_ytab : nullptr);
 }
 
