@@ -34,6 +34,7 @@ extern int g_ablate;
 extern int g_variant;
 extern int g_intile_small;
 extern int g_trsm_small_max;
+extern int g_min_units;
 extern unsigned long long *g_dbg;
 extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;

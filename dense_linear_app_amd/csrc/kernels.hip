@@ -449,7 +449,8 @@ __device__ __forceinline__ const T *panel_tile(const PanelRef &pan, int i, long 
 // of an XCD = one whole tile at mb = 1024 (or 64 / MT consecutive tiles of a smaller mb), so that
 // the blocks sharing operands run together behind one L2.  A launch of a few tiles (late waves;
 // every launch of a rank when the matrix is spread over 8 GPUs) uses smaller units, down to 8
-// blocks, so that all eight XCDs get the same share instead of whole tiles piling up on some.
+// blocks (until the launch has at least g_min_units units), so that all eight XCDs get the same
+// share instead of whole tiles piling up on some.
 // blocks_a = blocks of segment A (a multiple of 8 units).
 struct BlockMap {
   int2 ij;
@@ -1604,6 +1605,7 @@ int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU h
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
+int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
@@ -1615,7 +1617,7 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   const int nbm = C.mb / MACRO, MT = nbm * nbm, MTd = nbm * (nbm + 1) / 2;
   const long tot_a = (long)na * MT, tot_b = (long)nb * MTd;
   int unit = 64;  // blocks dealt to an XCD at a time (map_update_block)
-  while (unit > 8 && (tot_a + tot_b) / unit < 64) unit >>= 1;
+  while (unit > 8 && (tot_a + tot_b) / unit < g_min_units) unit >>= 1;
   long blocks_a = ((tot_a + unit - 1) / unit + 7) / 8 * 8 * unit;
   long blocks_b = ((tot_b + unit - 1) / unit + 7) / 8 * 8 * unit;
   if (na == 0 && nb == 1) blocks_a = 0, blocks_b = MTd;  // single diagonal tile: spread, no padding
