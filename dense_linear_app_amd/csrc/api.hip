@@ -245,7 +245,8 @@ int potrf_full_device(chol_desc *d, void *base) {
       // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
       const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
       const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
-      const bool yield = (double)u1_hi * t_tile < 6.0 * t_panel;
+      static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
+      const bool yield = (double)u1_hi * t_tile < yfac * t_panel;
       static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
       if (yield || split_always) {
         // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
