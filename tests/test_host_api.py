@@ -275,7 +275,8 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
     for t in ("d", "f"):
         upd = find("k_trail_updateI%sLb1E" % t)
         assert 2 * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
-        for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE"):
+        for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE",
+                      "k_solve_smallI%sE", "k_small_updateI%sE"):
             g = find(guest % t)
             assert g["vgprs"] + upd["vgprs"] <= 512, (guest % t, g, upd)
             assert g["lds"] + upd["lds"] <= 160 * 1024, (guest % t, g, upd)
