@@ -6,7 +6,9 @@ reference's metric, v6_test.c:60) on N MI355X of one node.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 ...
 
 A step is one factorisation of a freshly generated matrix that is already resident in HBM
-in tile layout (generation is outside the timed region whenever K copies fit in HBM).
+in tile layout; every step is timed in its own synchronised bracket and the K brackets are
+summed, generation happens between them.  The residual of the last step's factor is computed
+(untimed) and printed in the line.
 The matrix is the same for every GPU count (counter-based generator), so the N-GPU runs
 factor the SAME problem: strong scaling.  Rank 0 prints one JSON line.
 """
@@ -37,7 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-N", type=int, default=16384)
     ap.add_argument("--cpu-tile", type=int, default=512)
-    ap.add_argument("--check", action="store_true", help="verify the residual of the last step (untimed)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the (untimed) residual of the last step's factor; by default it is in the line")
     return ap.parse_args()
 
 
@@ -87,45 +90,36 @@ def run_single(a) -> dict:
     ch.CHAMELEON_Init(1, 1)
     N, B = a.N, a.tile
     dt = ch.ChamRealDouble if a.dtype == "f64" else ch.ChamRealFloat
-    esz = 8 if a.dtype == "f64" else 4
-    free, _total = torch.cuda.mem_get_info()
-    mat_bytes = N * N * esz
-    copies = max(1, min(a.steps, int(0.85 * free // mat_bytes)))
-    descs = [ch.CHAMELEON_Desc_Create(None, dt, B, B, B * B, N, N, 0, 0, N, N, 1, 1) for _ in range(copies)]
-    regen_inside = copies < a.steps
+    d = ch.CHAMELEON_Desc_Create(None, dt, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
     ch.set_profiling(False)
     for w in range(a.warmup):
-        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, descs[0], a.seed)
-        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, descs[0])
-        assert info == 0, info
-    for d in descs:
         ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
-    # timed region: exactly K steps; HIP events around every launch of the dominant kernel
-    ch.set_profiling(True)
-    upd_ms = upd_flops = 0.0
-    upd_launches = 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        d = descs[s % copies]
-        if regen_inside and s >= copies:
-            ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
         info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+        assert info == 0, info
+    # timed region: exactly K factorisations, each in its own synchronised bracket; the matrix is
+    # regenerated (in HBM, tile layout) BETWEEN the brackets, so nothing but the K factorisations
+    # is ever timed.  HIP events around every launch of the dominant kernel (library-side).
+    ch.set_profiling(True)
+    upd_ms = upd_flops = elapsed = 0.0
+    upd_launches = 0
+    for s in range(a.steps):
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)  # synchronous at the ABI (as Chameleon's _Tile calls)
+        torch.cuda.synchronize()
+        elapsed += time.perf_counter() - t0
+        assert info == 0, (s, info)
         st = ch.last_potrf_stats()
         upd_ms += st["update_ms"]
         upd_flops += st["update_flops"]
         upd_launches += st["update_launches"]
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert info == 0, info
     ch.set_profiling(False)
-    res = None
-    if a.check:
-        res = ch.residual_plgsy(descs[(a.steps - 1) % copies], float(N), a.seed)
-    for d in descs:
-        ch.CHAMELEON_Desc_Destroy(d)
+    # the factor the last timed step left in HBM, checked (untimed) against the regenerated matrix
+    res = ch.residual_plgsy(d, float(N), a.seed) if not a.no_check else None
+    ch.CHAMELEON_Desc_Destroy(d)
     return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
-            "regen_inside": regen_inside, "residual": res}
+            "residual": res}
 
 
 def run_multi(a) -> dict:
@@ -202,8 +196,6 @@ def main() -> int:
         "pct_of_mfma_peak": round(100.0 * tflops / (peak * a.gpus), 2),
     }
     if a.gpus == 1:
-        if r.get("regen_inside"):
-            line["config"]["note"] = "matrix regenerated inside the timed region (copies did not fit)"
         if r["upd_ms"] > 0:
             ach = r["upd_flops"] / (r["upd_ms"] * 1e-3) / 1e12
             traffic = load_pmc_traffic()

@@ -126,6 +126,14 @@ T *local_tile(const chol_desc *d, void *base, int I, int J) {
   return reinterpret_cast<T *>(base) + ((long)(I / d->p) + (long)(J / d->q) * d->lmt) * (long)d->bsizi;
 }
 
+// the context holds the inverses of at most 32 diagonal 128-blocks (tiles up to 4096): every entry
+// that factors, inverts or solves with a tile checks this before any launch writes winv
+bool winv_fits(const chol_desc *d) {
+  return (size_t)(roundup(d->mbi, MACRO) / MACRO) * MACRO * MACRO * d->esize <= g.winv_bytes;
+}
+#define CHECK_WINV(d, what) \
+  if (!winv_fits(d)) return fail(CHOL_ERR_NOT_SUPPORTED, what ": tile size above 4096")
+
 bool single_tile_square(const chol_desc *d) {
   return d->mt == 1 && d->nt == 1 && d->m == d->n && d->mb == d->nb && d->m == d->mb &&
          d->p == 1 && d->q == 1 && d->i == 0 && d->j == 0;
@@ -333,6 +341,7 @@ int build_worklist(chol_desc *d) {
 
 template <typename T>
 static int potrf_impl(chol_desc *A) {
+  CHECK_WINV(A, "potrf_tile");
   if (single_tile_square(A)) {
     Staged st;
     int rc = stage_in<T>(A, 0, /*identity_pad=*/true, &st);
@@ -351,8 +360,6 @@ static int potrf_impl(chol_desc *A) {
     return fail(CHOL_ERR_NOT_SUPPORTED,
                 "potrf_tile on a distributed descriptor: use the chol_wave_* building blocks");
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
-  if ((size_t)(A->mbi / MACRO) * MACRO * MACRO * sizeof(T) > g.winv_bytes)
-    return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: tile size above 4096");
   if (A->on_device) return potrf_full_device<T>(A, A->mat);
   // host-resident tiled matrix: stage the whole matrix through HBM
   if (A->padded) return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: padded image over a host buffer");
@@ -375,6 +382,7 @@ static int potrf_impl(chol_desc *A) {
 
 template <typename T>
 static int trsm_impl(double alpha, chol_desc *L, chol_desc *B) {
+  CHECK_WINV(L, "trsm_tile");
   Staged sl, sb;
   int rc = stage_in<T>(L, 0, /*identity_pad=*/true, &sl);
   if (rc) return rc;
@@ -599,7 +607,9 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
   d->mbi = mb;
   d->bsizi = bsiz;
   d->padded = false;
-  if (multi && (lm % mb || ln % nb || mb % MACRO)) {
+  // a matrix smaller than its one tile (lm < mb): same treatment as a ragged edge tile
+  const bool partial1 = !multi && (lm != mb || ln != nb);
+  if ((multi && (lm % mb || ln % nb || mb % MACRO)) || partial1) {
     // ragged order and/or a tile edge that is not a multiple of 128 (the reference's sweep
     // uses NB = 192 ... 448): the library keeps its own image with tiles rounded up to 128
     // and the identity outside the matrix.  Needs library-owned storage on one process.
@@ -638,7 +648,7 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
       (void)hipStreamSynchronize(g.s_main);
     }
   }
-  if (multi) {
+  if (multi || d->padded) {
     int rc = build_worklist(d);
     if (rc) {
       if (d->owns) (void)hipFree(d->mat);
@@ -760,7 +770,7 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
   const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
   if (!A) return fail(-3, "plgsy_tile: NULL descriptor");
   if (!A->on_device) return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: descriptor must be device-resident");
-  if (A->mt == 1 && A->nt == 1 && (A->m != A->mb || A->n != A->nb))
+  if (A->mt == 1 && A->nt == 1 && (A->m != A->mb || A->n != A->nb) && !A->padded)
     return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: partial single tile");
   std::lock_guard<std::mutex> lk(g_mu);
   const LocalMat L = local_mat(A, A->mat);
@@ -908,8 +918,7 @@ int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
   if (B->lm != A->lm || B->mb != A->mb || B->mbi != A->mbi || B->dtype != A->dtype)
     return fail(-3, "potrs_tile: B must have A's order, tile size and type");
   if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: stored tile edge must be a multiple of 64");
-  if ((size_t)(A->mbi / MACRO) * MACRO * MACRO * A->esize > g.winv_bytes)
-    return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: tile size above 4096");
+  CHECK_WINV(A, "potrs_tile");
   std::lock_guard<std::mutex> lk(g_mu);
   return A->dtype == CHOL_REAL_DOUBLE ? potrs_impl<double>(A, B) : potrs_impl<float>(A, B);
 }
@@ -1139,6 +1148,7 @@ int chol_reset_info(void) {
 int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_potrf before chol_init");
   if (!d || !lkk) return fail(-1, "wave_potrf: NULL");
+  CHECK_WINV(d, "wave_potrf");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
     launch_potrf_tile<double>(s, (double *)lkk, d->mbi, (double *)g.winv, g.d_info, k * d->mbi);
@@ -1151,6 +1161,7 @@ int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
 int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_invert_diag before chol_init");
   if (!d || !lkk) return fail(-1, "wave_invert_diag: NULL");
+  CHECK_WINV(d, "wave_invert_diag");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
     launch_invert_diag<double>(s, (const double *)lkk, d->mbi, (double *)g.winv);
@@ -1184,6 +1195,7 @@ int chol_wave_import_winv(chol_desc_t *d, const void *src, void *stream) {
 int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_trsm before chol_init");
   if (!d || !lkk) return fail(-1, "wave_trsm: NULL");
+  CHECK_WINV(d, "wave_trsm");
   if (k % d->q != d->pcol) return 0;  // this process column holds no tile of panel k
   hipStream_t s = (hipStream_t)stream;
   const int il0 = (k + d->p - d->prow) / d->p;  // first local row with global index > k

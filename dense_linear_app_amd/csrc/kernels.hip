@@ -1203,6 +1203,13 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
               DEFER(8); DEFER(9); PIN2(rinv, 8, 9);
               sq = (T)__builtin_fma(cc, h, g);
               DEFER(10); DEFER(11); DEFER(12); DEFER(13);
+              // +Inf passes `d > 0` in LAPACK too (dpotf2: sqrt(Inf) = Inf, the column is scaled by
+              // 1/Inf = 0, info stays 0); v_rsq(Inf) = 0 would turn it into NaN here.  d is
+              // wave-uniform (SGPRs): a scalar compare and two selects
+              if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0) {
+                sq = (T)__builtin_huge_val();
+                rinv = T(0);
+              }
 #undef PIN2
             } else {
               if constexpr (jj >= 1) prev.wait();

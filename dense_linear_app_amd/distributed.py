@@ -72,17 +72,24 @@ class HipEngine:
         self.prow, self.pcol = rank // Q, rank % Q
         self.tdtype = torch.float64 if dtype == "f64" else torch.float32
         self.cdtype = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
-        if device is not None:
-            ch.set_device(device)
+        # ONE device index for torch (tile storage, collectives) and for libcholmi (kernels):
+        # the argument, else $LOCAL_RANK (what chol_init itself would pick), else cuda:0
+        if device is None:
+            import os
+
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        ch.set_device(device)
         ch.set_rank(rank, P * Q)
         ch.CHAMELEON_Init(1, 1)
-        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.dev = torch.device("cuda", device)
         self.lmt = max(0, (self.nt - self.prow + P - 1) // P)
         self.lnt = max(0, (self.nt - self.pcol + Q - 1) // Q)
         self.bsiz = B * B
         self.store = torch.empty(max(1, self.lmt * self.lnt) * self.bsiz, dtype=self.tdtype, device=self.dev)
         self.desc = ch.CHAMELEON_Desc_Create(self.store, self.cdtype, B, B, self.bsiz, N, N, 0, 0, N, N, P, Q)
         assert self.desc.local_tiles() == (self.lmt, self.lnt)
+        assert self.store.device.index == device
 
     # -- storage
     def empty_tiles(self, n: int):

@@ -181,3 +181,57 @@ def test_plain_c_driver_reproduces_reference_outputs():
         assert m and m.group(1) == "%.2e" % float(gold[N, NB]), r.stdout
         m = re.search(r"\|\|A - L L\^T\|\|_F / \|\|A\|\|_F = ([0-9.e+-]+)", r.stdout)
         assert m and float(m.group(1)) <= 1e-13, r.stdout
+
+
+def test_tile_above_workspace_capacity_is_refused(cham):
+    """The context holds the inverses of 32 diagonal 128-blocks (tiles up to 4096 in fp64): a larger
+    tile must be refused by every entry that would write that workspace -- never an out-of-bounds
+    device write (B comes straight from the worker's JSON payload)."""
+    from dense_linear_app_amd._lib import lib
+
+    ch, L = cham, lib()
+    B = 4224
+    a = np.zeros((B, B), order="F")
+    a[np.arange(B), np.arange(B)] = 2.0
+    rc, d = _desc(L, a)
+    assert rc == 0
+    before = a.copy()
+    assert L.chol_potrf_tile(ch.ChamLower, d) == -104 and b"4096" in L.chol_last_error()
+    assert L.chol_trsm_tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, d, d) == -104
+    assert L.chol_wave_potrf(d, 0, a.ctypes.data, None) == -104
+    assert L.chol_wave_invert_diag(d, a.ctypes.data, None) == -104
+    assert L.chol_wave_trsm(d, 0, a.ctypes.data, None) == -104
+    assert np.array_equal(a, before)
+    assert L.chol_desc_destroy(C.byref(d)) == 0
+    # the largest tile that fits still works
+    B = 4096
+    a = np.zeros((B, B), order="F")
+    a[np.arange(B), np.arange(B)] = 4.0
+    rc, d = _desc(L, a)
+    assert rc == 0 and L.chol_potrf_tile(ch.ChamLower, d) == 0
+    assert np.array_equal(np.diag(a), np.full(B, 2.0))
+    assert L.chol_desc_destroy(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("n,mb", [(150, 200), (100, 128), (300, 512)])
+def test_matrix_smaller_than_its_single_tile(cham, orc, n, mb):
+    """mt = nt = 1 with lm < mb (a ragged edge tile that is also the only tile): served from the
+    padded library-owned image like every other ragged shape, refused over a user buffer."""
+    ch = cham
+    rng = np.random.default_rng(n)
+    M = rng.uniform(-0.5, 0.5, (n, n))
+    A = np.asfortranarray(M @ M.T + n * np.eye(n))
+    d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, mb, mb, mb * mb, n, n, 0, 0, n, n, 1, 1)
+    d.from_lapack(A)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    out = d.to_lapack()
+    Lref, info = orc.dpotrf(A)
+    assert info == 0
+    assert np.abs(np.tril(out) - np.tril(Lref)).max() <= 16 * n * np.finfo(float).eps * np.abs(Lref).max()
+    assert np.array_equal(np.triu(out, 1), np.triu(A, 1))
+    bad = A.copy(order="F")
+    bad[n - 3, n - 3] = -1.0
+    d.from_lapack(bad)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == n - 2
+    with pytest.raises(ch.CholmiError, match="ragged"):
+        ch.CHAMELEON_Desc_Create(np.zeros(mb * mb), ch.ChamRealDouble, mb, mb, mb * mb, n, n, 0, 0, n, n, 1, 1)

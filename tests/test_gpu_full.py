@@ -126,9 +126,10 @@ def test_full_potrf_fp32(cham, orc):
     assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-4
 
 
-@pytest.mark.parametrize("N,B", [(16384, 512), (32768, 1024)])
+@pytest.mark.parametrize("N,B", [(16384, 512), (32768, 512), (32768, 1024)])
 def test_full_potrf_large_properties(cham, N, B):
-    """BASELINE sizes: residual of the regenerated matrix, idempotent regeneration, positivity."""
+    """BASELINE configs 2 (16384/512) and 3 (32768/512) and the headline's smaller sibling:
+    residual of the regenerated matrix, idempotent regeneration, positivity."""
     ch = cham
     d = full_desc(ch, N, B)
     ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
@@ -139,10 +140,11 @@ def test_full_potrf_large_properties(cham, N, B):
         assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
 
 
-@pytest.mark.parametrize("N,B,dtype,tol", [(65536, 1024, "f64", 1e-13), (65536, 1024, "f32", 5e-5)])
+@pytest.mark.parametrize("N,B,dtype,tol", [(65536, 1024, "f64", 1e-13), (65536, 1024, "f32", 5e-5),
+                                           (131072, 1024, "f32", 5e-5)])
 def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
-    """BASELINE configs 4/5 at their per-matrix size on one GPU: factor, residual of the
-    regenerated matrix, positive finite diagonal, untouched strictly-upper tile."""
+    """BASELINE configs 4 (N=65536 fp64) and 5 (N=131072 fp32, 64 GiB) in full on one GPU: factor,
+    residual of the regenerated matrix, positive finite diagonal, untouched strictly-upper tile."""
     ch = cham
     dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
     d = full_desc(ch, N, B, dt)
