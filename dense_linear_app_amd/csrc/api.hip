@@ -44,7 +44,7 @@ struct Ctx {
   bool inited = false;
   int device = -1;
   int rank = 0, nranks = 1;
-  hipStream_t s_main = nullptr, s_panel = nullptr, s_trsm = nullptr;
+  hipStream_t s_main = nullptr, s_panel = nullptr, s_trsm = nullptr, s_u1 = nullptr;
   void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k)
   size_t winv_bytes = 0;
   int *d_info = nullptr;
@@ -196,105 +196,237 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
 }
 
 // ---- whole-matrix right-looking tiled Cholesky on one GPU --------------------
+// Reference order (C2:506-565): POTRF(k); TRSM(i,k), i > k; SYRK / GEMM (i,j,k), k < j <= i.  Here, per
+// wave k, four streams:
+//   s_panel (high)  POTRF(k) as mb/128 diagonal-block steps
+//   s_trsm  (high)  the TRSM steps of panel k, one 128-column step behind the POTRF steps
+//   s_u1    (mid)   U1(k): column k+1 by panel k -- the diagonal tile (k+1,k+1) first (POTRF(k+1) waits
+//                   for nothing else), then the rest of the column (TRSM(k+1) waits for that)
+//   s_main  (low)   U2(k): the columns beyond, beside U1(k): the two touch different tiles, U1's
+//                   blocks go first and U2's fill whatever U1 -- at most one round of workgroups
+//                   on a mid-size matrix -- leaves idle
+// U1(k) waits for U2(k-1), whose range includes column k+1; U2(k) follows U2(k-1) in stream order.
 template <typename T>
 int potrf_full_device(chol_desc *d, void *base) {
   const int nt = d->nt, mb = d->mbi;
   const long bsiz = d->bsizi;
   T *M = reinterpret_cast<T *>(base);
   T *winv = reinterpret_cast<T *>(g.winv);
-  const int nbm_ev = mb / MACRO;
-  int rc = ensure_events(2 * (size_t)nt + 8 + nbm_ev + 5 * (size_t)nt);
+  const int nbm = mb / MACRO;
+  enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_PER_WAVE };
+  enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
+  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm);
   if (rc) return rc;
+  auto ev = [&](int k, int which) { return g.events[(size_t)E_PER_WAVE * k + which]; };
+  hipEvent_t *fixed = &g.events[(size_t)E_PER_WAVE * nt];
+  hipEvent_t *ev_steps = fixed + F_FIXED;
+  static const bool concurrent = !(getenv("CHOLMI_U1_CONCURRENT") && atoi(getenv("CHOLMI_U1_CONCURRENT")) == 0);
+  // tiles up to this edge are updated by two panels per pass (short K-loops pay the per-block
+  // prologue / epilogue / C traffic twice as often)
+  static const int pair_max_mb = getenv("CHOLMI_PAIR_MAX_MB") ? atoi(getenv("CHOLMI_PAIR_MAX_MB")) : 1024;
+  // ... while a wave's update is at least this many panel chains long: deferring half the updates
+  // leaves the chip short of work once the panel chain is what a wave waits for
+  static const double pair_fac = getenv("CHOLMI_PAIR_FACTOR") ? atof(getenv("CHOLMI_PAIR_FACTOR")) : 2.0;
+  bool paired = false, cols_pending = false;  // paired: this wave belongs to a pair (decided at its even wave)
+  int open_bracket = -1;                      // odd wave whose profiling bracket is still open
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
-  hipEvent_t ev_start = g.events[2 * nt], ev_stop = g.events[2 * nt + 1], ev_join = g.events[2 * nt + 2];
-  hipEvent_t ev_wave = g.events[2 * nt + 3], ev_trsm = g.events[2 * nt + 4];
-  hipEvent_t *ev_steps = &g.events[2 * nt + 8 + 4 * nt];
-  hipEvent_t *ev_u1r = &g.events[2 * nt + 8 + 4 * nt + nbm_ev];  // rest of column k+1 updated (one per wave)
-  HIPCHECK(hipEventRecord(ev_start, g.s_main));
-  HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_start, 0));
+  HIPCHECK(hipEventRecord(fixed[F_START], g.s_main));
+  HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_START], 0));
+  HIPCHECK(hipStreamWaitEvent(g.s_u1, fixed[F_START], 0));
   const LocalMat C = local_mat(d, base);
+  const double b3 = (double)mb * mb * mb;
   double upd_flops = 0;
   int upd_launches = 0;
   for (int k = 0; k < nt; ++k) {
-    hipEvent_t ev_panel = g.events[2 * k], ev_u1 = g.events[2 * k + 1];
-    HIPCHECK(hipEventRecord(ev_wave, g.s_panel));  // s_panel has waited for the SYRK on (k,k) by panel k-1
-    // panel stream: POTRF(k,k) then TRSM(i,k), i > k  (C2:510-535)
-    T *lkk = M + ((long)k + (long)k * nt) * bsiz;
+    HIPCHECK(hipEventRecord(fixed[F_WAVE], g.s_panel));  // s_panel has waited for the SYRK on (k,k) by panel k-1
     // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream, which
-    // also needs the rest of column k updated by panel k-1
-    HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev_wave, 0));
-    if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev_u1r[k - 1], 0));
+    // also needs the rest of column k updated by panel k-1  (C2:510-535)
+    T *lkk = M + ((long)k + (long)k * nt) * bsiz;
+    HIPCHECK(hipStreamWaitEvent(g.s_trsm, fixed[F_WAVE], 0));
+    if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev(k - 1, E_U1R), 0));
     launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv, g.d_info, k * mb, lkk + bsiz, bsiz,
-                              nt - 1 - k);
-    HIPCHECK(hipEventRecord(ev_trsm, g.s_trsm));
-    HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_trsm, 0));
-    HIPCHECK(hipEventRecord(ev_panel, g.s_panel));
-    // main stream: trailing update (C2:540-560); column k+1 first so that the
-    // next panel can start while the rest of the update is still running
-    HIPCHECK(hipStreamWaitEvent(g.s_main, ev_panel, 0));
-    if (k + 1 < nt) {
-      PanelRef pan;
-      memset(&pan, 0, sizeof pan);
-      pan.P = 1;
-      pan.base[0] = M + (long)k * nt * bsiz;
-      pan.first[0] = 0;
-      const ColRange r1 = col_range(d, k + 1, k + 2 <= nt ? k + 2 : nt), r2 = col_range(d, k + 2 <= nt ? k + 2 : nt, nt);
-      const int u1_hi = r1.na + r1.nb + r2.na + r2.nb;  // tiles of this wave's update
-      hipEvent_t p0 = nullptr, p1 = nullptr, p2 = nullptr;
-      if (g.profiling) {
-        p0 = g.events[2 * nt + 8 + 3 * k];
-        p1 = g.events[2 * nt + 8 + 3 * k + 1];
-        p2 = g.events[2 * nt + 8 + 3 * k + 2];
-        HIPCHECK(hipEventRecord(p0, g.s_main));
-      }
-      // Give CUs to the next panel's guest workgroups only when that panel is on the critical
-      // path, i.e. when this wave's update is not much longer than a panel (POTRF ~ (mb/128) x
-      // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
-      const double t_tile = 2.0 * mb * (double)mb * mb / 65e12;
-      const double t_panel = (mb / MACRO) * 130e-6 * 1.5;
-      static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
-      const bool yield = (double)u1_hi * t_tile < yfac * t_panel;
-      static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
-      if (yield || split_always) {
-        // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
-        // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
-        if (cholmi::g_intile_small)
-          launch_diag_syrk<T>(g.s_main, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
-                              M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
-        else
-          launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
-        HIPCHECK(hipEventRecord(ev_u1, g.s_main));
-        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
-        HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
-        if (r1.na > 0) ++upd_launches;
-      } else {
-        // the update dwarfs the panel: one launch for the whole column (one tail less per wave)
-        launch_trail_update<T>(g.s_main, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
-        HIPCHECK(hipEventRecord(ev_u1, g.s_main));
-        HIPCHECK(hipEventRecord(ev_u1r[k], g.s_main));
-      }
-      HIPCHECK(hipStreamWaitEvent(g.s_panel, ev_u1, 0));
-      if (g.profiling) HIPCHECK(hipEventRecord(p1, g.s_main));
-      if (r2.na + r2.nb > 0) {
-        launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
-        ++upd_launches;
-      }
-      if (g.profiling) HIPCHECK(hipEventRecord(p2, g.s_main));
-      // (launches of k_trail_update: the diagonal-tile SYRK of the split form is a k_small_update)
-      if (!((yield || split_always) && cholmi::g_intile_small)) ++upd_launches;
-      // algorithmic flops of this wave's update: GEMM 2B^3 per off-diagonal tile,
-      // SYRK B^3 per diagonal tile
-      const double ntl = (double)(nt - 1 - k);
-      upd_flops += (ntl * (ntl - 1) / 2 * 2.0 + ntl * 1.0) * (double)mb * mb * mb;
+                              nt - 1 - k, fixed[F_HEAD]);
+    HIPCHECK(hipEventRecord(fixed[F_TRSM], g.s_trsm));
+    HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_TRSM], 0));
+    HIPCHECK(hipEventRecord(ev(k, E_PANEL), g.s_panel));
+    if (k + 1 >= nt) break;
+    // trailing update (C2:540-560)
+    auto panel_ref = [&](int kk) {
+      PanelRef pr;
+      memset(&pr, 0, sizeof pr);
+      pr.P = 1;
+      pr.base[0] = M + (long)kk * nt * bsiz;
+      return pr;
+    };
+    const PanelRef pan = panel_ref(k);
+    if ((k & 1) == 0) {
+      const double m = nt - 1 - k;
+      paired = mb <= pair_max_mb && k + 2 < nt &&
+               m * (m + 1) / 2 * (2.0 * b3 / 65e12) >= pair_fac * (nbm * 130e-6 * 1.5);
     }
+    if (paired) {
+      // Panels in pairs (k-1, k), k odd: the far columns' update by the even panel is deferred and
+      // applied together with the odd one in ONE pass of twice the K (k_trail_update, npan = 2).
+      //   even k:  U1(k)  = column k+1 by panel k                                       (s_u1)
+      //   odd  k:  U1'(k) = column k+1, Ca = column k+2, Cb = column k+3 by panels k-1, k  (s_u1, in this order)
+      //            big(k) = the columns from k+4 on by panels k-1, k                      (s_main, beside them)
+      // Every column is written by launches of s_u1 in program order, except by big(); the first
+      // launches of s_u1 on a column big(k) covers are Ca / Cb of wave k+2, which wait for it.
+      // POTRF(k+1) waits for the SYRKs on (k+1,k+1) only, TRSM(k+1) for the rest of column k+1.
+      const bool odd = (k & 1) != 0;
+      const PanelRef prev = panel_ref(odd ? k - 1 : k);
+      const PanelRef *p2 = odd ? &pan : nullptr;       // launches: first `prev`, then `pan` when odd
+      const PanelRef &p1 = odd ? prev : pan;
+      auto rng = [&](int jlo, int jhi) { return col_range(d, jlo < nt ? jlo : nt, jhi < nt ? jhi : nt); };
+      const ColRange c1 = rng(k + 1, k + 2), ca = rng(k + 2, k + 3), cb = rng(k + 3, k + 4), big = rng(k + 4, nt);
+      const int wave_tiles = c1.na + c1.nb + (odd ? ca.na + ca.nb + cb.na + cb.nb + big.na + big.nb : 0);
+      const double t_tile = 2.0 * b3 / 65e12 * (odd ? 2 : 1), t_panel = nbm * 130e-6 * 1.5;
+      static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
+      const bool yield = (double)wave_tiles * t_tile < yfac * t_panel * (odd ? 2 : 1);
+      hipStream_t su = concurrent ? g.s_u1 : g.s_main;
+      T *ckk = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
+      if (cholmi::g_intile_small) {
+        if (odd) launch_diag_syrk<T>(su, ckk, M + ((long)(k + 1) + (long)(k - 1) * nt) * bsiz, mb);
+        HIPCHECK(hipStreamWaitEvent(su, fixed[F_HEAD], 0));  // the head tile L(k+1,k) is all the last SYRK needs
+        launch_diag_syrk<T>(su, ckk, M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
+      } else {
+        HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
+        launch_trail_update<T>(su, C, d->d_list, c1.off, 0, c1.offb, c1.nb, p1, yield, p2);
+      }
+      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
+      HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
+      HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
+      if (!odd && open_bracket < 0 && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), su));
+      launch_trail_update<T>(su, C, d->d_list, c1.off, c1.na, c1.offb, 0, p1, yield, p2);
+      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
+      int timed = 0;
+      double fl = 0;
+      if (odd) {
+        if (c1.na > 0) ++timed, fl += 2.0 * c1.na;
+        if (k >= 2) HIPCHECK(hipStreamWaitEvent(su, ev(k - 2, E_U2), 0));  // big(k-2) covered these columns
+        launch_trail_update<T>(su, C, d->d_list, ca.off, ca.na, ca.offb, ca.nb, p1, yield, p2);
+        launch_trail_update<T>(su, C, d->d_list, cb.off, cb.na, cb.offb, cb.nb, p1, yield, p2);
+        if (ca.na + ca.nb > 0) ++timed, fl += 2.0 * ca.na + ca.nb;
+        if (cb.na + cb.nb > 0) ++timed, fl += 2.0 * cb.na + cb.nb;
+        HIPCHECK(hipEventRecord(fixed[F_COLS], su));
+        cols_pending = true;
+        HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
+        if (g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
+        launch_trail_update<T>(g.s_main, C, d->d_list, big.off, big.na, big.offb, big.nb, p1, yield, p2);
+        if (big.na + big.nb > 0) ++timed, fl += 2.0 * big.na + big.nb;
+        HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
+        // the bracket [P0(k), P1(k)] covers every k_trail_update launch of the pair's update: the
+        // two-panel launches of this wave, which start together, and U1(k+1), which runs beside
+        // big(k); it is closed at the next wave
+        open_bracket = k;
+        upd_launches += timed;
+        upd_flops += 2.0 * fl * b3;  // two panels per pass
+      } else {
+        HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
+        if (g.profiling) {
+          if (open_bracket >= 0) {
+            // waiting for the column launches and for U1(k) on s_main constrains nothing: big(k+1)
+            // needs panel k+1, which comes after all of them
+            HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
+            HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
+            HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
+            HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
+            HIPCHECK(hipEventRecord(ev(k, E_P1), g.s_main));
+          } else {
+            HIPCHECK(hipEventRecord(ev(k, E_P1), su));  // the very first wave: U1(0) alone, bracketed on its stream
+          }
+        }
+        open_bracket = -1;
+        if (c1.na > 0) ++upd_launches, upd_flops += 2.0 * c1.na * b3;
+      }
+      continue;
+    }
+    if (open_bracket >= 0) {  // the paired phase ended on an odd wave: close its bracket
+      if (g.profiling) {
+        HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
+        HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
+      }
+      open_bracket = -1;
+    }
+    const int j2 = k + 2 <= nt ? k + 2 : nt;
+    const ColRange r1 = col_range(d, k + 1, j2), r2 = col_range(d, j2, nt);
+    // Give CUs to the next panel's guest workgroups only when that panel is on the critical
+    // path, i.e. when this wave's update is not much longer than a panel (POTRF ~ (mb/128) x
+    // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
+    const double t_tile = 2.0 * b3 / 65e12;
+    const double t_panel = nbm * 130e-6 * 1.5;
+    static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
+    const bool yield = (double)(r1.na + r1.nb + r2.na + r2.nb) * t_tile < yfac * t_panel;
+    static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
+    const bool split = yield || split_always;
+    hipStream_t su = concurrent ? g.s_u1 : g.s_main;
+    // the SYRK on (k+1,k+1) needs the head tile L(k+1,k) only; everything else the whole panel
+    HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
+    if (cols_pending) {  // first plain wave after the paired phase: Cb of the last pair wrote column k+2
+      HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
+      cols_pending = false;
+    }
+    if (concurrent) {
+      if (k > 0) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));  // column k+1 was in U2(k-1)'s range
+      HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
+    } else if (g.profiling) {
+      HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
+    }
+    int timed = 0;  // k_trail_update launches inside this wave's profiling bracket
+    if (split) {
+      // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
+      // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
+      if (cholmi::g_intile_small) {
+        launch_diag_syrk<T>(su, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
+                            M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
+      } else {
+        launch_trail_update<T>(su, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
+        ++timed;
+      }
+      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
+      HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
+      launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
+      if (r1.na > 0) ++timed;
+      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
+    } else {
+      // the update dwarfs the panel: one launch for the whole column (one tail less per wave)
+      launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
+      ++timed;
+      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
+      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
+    }
+    HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
+    if (concurrent && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
+    if (r2.na + r2.nb > 0) {
+      launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
+      ++timed;
+    }
+    HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
+    if (g.profiling) {
+      // the bracket [P0, P1] on s_main covers every k_trail_update launch of the wave: U1(k) started
+      // with U2(k); waiting for its end here constrains nothing (U2(k+1) needs panel k+1, which needs it)
+      if (concurrent) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
+      HIPCHECK(hipEventRecord(ev(k, E_P1), g.s_main));
+    }
+    upd_launches += timed;
+    // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
+    // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
+    upd_flops += (2.0 * r2.na + r2.nb) * b3;
+    upd_flops += (2.0 * r1.na + ((split && cholmi::g_intile_small) ? 0 : r1.nb)) * b3;
   }
-  HIPCHECK(hipEventRecord(ev_join, g.s_panel));
-  HIPCHECK(hipStreamWaitEvent(g.s_main, ev_join, 0));
-  HIPCHECK(hipEventRecord(ev_stop, g.s_main));
+  if (open_bracket >= 0 && g.profiling) {
+    HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
+    HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
+  }
+  HIPCHECK(hipEventRecord(fixed[F_JOIN], g.s_panel));
+  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_JOIN], 0));
+  HIPCHECK(hipEventRecord(fixed[F_U1END], g.s_u1));
+  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_U1END], 0));
+  HIPCHECK(hipEventRecord(fixed[F_STOP], g.s_main));
   HIPCHECK(hipStreamSynchronize(g.s_main));
   float ms = 0;
-  HIPCHECK(hipEventElapsedTime(&ms, ev_start, ev_stop));
+  HIPCHECK(hipEventElapsedTime(&ms, fixed[F_START], fixed[F_STOP]));
   g.total_ms = ms;
   g.update_flops = upd_flops;
   g.update_launches = upd_launches;
@@ -302,7 +434,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   if (g.profiling) {
     for (int k = 0; k + 1 < nt; ++k) {
       float a = 0;
-      HIPCHECK(hipEventElapsedTime(&a, g.events[2 * nt + 8 + 3 * k], g.events[2 * nt + 8 + 3 * k + 2]));
+      HIPCHECK(hipEventElapsedTime(&a, ev(k, E_P0), ev(k, E_P1)));
       g.update_ms += a;
     }
   }
@@ -520,10 +652,14 @@ int chol_init(int ncpu, int ngpu) {
   HIPCHECK(hipStreamCreateWithPriority(&g.s_main, hipStreamNonBlocking, lo));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
   HIPCHECK(hipStreamCreateWithPriority(&g.s_trsm, hipStreamNonBlocking, hi));
+  // the update of column k+1 (what the next panel waits for) runs beside the rest of the wave's
+  // update, ahead of it in priority
+  HIPCHECK(hipStreamCreateWithPriority(&g.s_u1, hipStreamNonBlocking, lo - 1 > hi ? lo - 1 : hi));
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
+  if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
@@ -561,10 +697,11 @@ int chol_finalize(void) {
   (void)hipStreamDestroy(g.s_main);
   (void)hipStreamDestroy(g.s_panel);
   (void)hipStreamDestroy(g.s_trsm);
+  (void)hipStreamDestroy(g.s_u1);
   g.winv = nullptr;
   g.d_info = nullptr;
   g.d_acc = nullptr;
-  g.s_main = g.s_panel = g.s_trsm = nullptr;
+  g.s_main = g.s_panel = g.s_trsm = g.s_u1 = nullptr;
   g.inited = false;
   return 0;
 }

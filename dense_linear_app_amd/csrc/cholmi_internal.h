@@ -35,6 +35,7 @@ extern int g_variant;
 extern int g_intile_small;
 extern int g_trsm_small_max;
 extern int g_min_units;
+extern int g_trsm_fused_min;
 extern unsigned long long *g_dbg;
 extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;
@@ -43,10 +44,11 @@ constexpr int YTAB_ENTRIES = 2048;
 // C(i,j) -= L(i,k) L(j,k)^T for the (i,j) pairs in d_list[off .. off+na) followed by
 // d_list[offb .. offb+nb) (off-diagonal tiles first, the diagonal tiles -- whose blocks above the
 // diagonal exit at once -- last, so that they do not split the 64-block cohorts of an XCD);
-// yield: the update's waves give their CU to guest workgroups of the panel chain (kernels.hip)
+// yield: the update's waves give their CU to guest workgroups of the panel chain (kernels.hip);
+// pan2 != null: the updates by two panels in one pass (C -= L L^T of `pan`, then of `pan2`)
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield = false);
+                         int nb, const PanelRef &pan, bool yield = false, const PanelRef *pan2 = nullptr);
 
 // In-tile blocked POTRF of one mb x mb tile (device pointer, ld = mb).  Writes the
 // inverses of the MACRO x MACRO diagonal blocks of L to winv (mb/MACRO blocks of
@@ -60,10 +62,12 @@ template <typename T>
 void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 
 // POTRF(tile) on stream sp with the TRSM of `ntiles` contiguous tiles pipelined behind it on
-// stream st (ev: mb/MACRO events).  The caller joins both streams.
+// stream st (ev: mb/MACRO events).  ev_head (may be null): recorded on st once the FIRST panel tile is
+// solved (a long panel's other tiles follow in one throughput-form launch).  The caller joins both streams.
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
-                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles);
+                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles,
+                            hipEvent_t ev_head = nullptr);
 
 // winv from an already factored tile
 template <typename T>

@@ -57,6 +57,16 @@ struct Tr<float> {
 constexpr int BK = 16;
 constexpr int LROW = MACRO + 16;
 
+// compile-time loop (indices usable as constants inside the body)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+
 template <typename T>
 struct alignas(16) Smem {
   T a[2][BK][LROW];
@@ -524,10 +534,14 @@ __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const 
   nt_epilogue<T>(Cp, C.mb, acc, T(-1), (ablate & 4) ? T(0) : T(1), diag && mi == mj, 0, 0);
 }
 
+// npan = 2: the updates by two consecutive panels in one pass, C(i,j) -= L(i,k-1) L(j,k-1)^T +
+// L(i,k) L(j,k)^T -- one K-loop of twice the length per C block (the walker defers the far columns'
+// update by the even panel of a pair): half the C traffic, prologues and epilogues per flop.
 template <typename T, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
                                                            int na, int offb, int nb, int blocks_a, PanelRef pan,
-                                                           int nbm, int unit, const int *ytab) {
+                                                           int nbm, int unit, const int *ytab, PanelRef pan2,
+                                                           int npan) {
   __shared__ SmemP<T> sm;
   BlockMap bm;
   if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
@@ -540,7 +554,11 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
           mi * MACRO + (long)mj * MACRO * C.mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, ytab ? ytab + cu_slot() : nullptr);
+  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
+  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, yslot);
+  if (npan > 1)
+    nt_kloop_paired<T, DMA>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
+                            panel_tile<T>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
   if (diag && mi == mj)
     nt_epilogue_paired_impl<T, true>(Cp, C.mb, acc, T(-1), T(1));
   else
@@ -588,6 +606,188 @@ __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, in
   nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
   nt_epilogue_paired<T>(Cp, mb, acc, T(-1), beta, false);
   guest.leave();
+}
+
+// ------------------------------------------------------------------------------
+// Panel TRSM, throughput form (fp64):  X(i,k) = A(i,k) L(k,k)^{-T}  for many tiles in ONE launch, in
+// place.  One workgroup per 128-row block of a tile, left-looking over the 128-column blocks c:
+//     X[:,c] = (A[:,c] - sum_{s<c} X[:,s] L(c,s)^T) Winv_c^T
+// -- the arithmetic of the stepwise form (k_panel_solve + k_panel_update: products with the inverted
+// 128 x 128 diagonal blocks), but the sum over s is ONE K-loop of length 128 c (X[:,0:128c] and
+// L(c,0:128c) are contiguous column ranges), nothing is read-modify-written per step, and a wave of
+// the DAG needs one launch instead of 2 nbm.  The stepwise form moves every block of the tile
+// through HBM/L2 once per step (16 flop/B) and runs at 25-50 % MFMA utilisation, which is what the
+// trailing update loses when the two share the chip.
+// Wave w owns rows 32w..32w+31 and ALL 128 columns of the block, so that the second product needs
+// no LDS round trip: with the operands passed swapped, lane (i, q) holds in accumulator register r of
+// tile (a, b) the element (row 32w + 2i + a, column n = 32(b>>1) + 8r + 2q + (b&1)) -- exactly the
+// value the 16x16x4 MFMA wants from it as the k = n operand of the next product, T Winv^T.
+// The second product runs in two passes of 64 output columns (accumulators: 128 + 64 VGPRs).
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_trsm_fused(T *tiles, long bsiz, int mb, int nbm,
+                                                       const T *__restrict__ lkk, const T *__restrict__ winv) {
+  static_assert(sizeof(T) == 8, "fp64 only: the fp32 fragment pairing covers 64 rows");
+  using vec_t = typename Tr<T>::vec_t;
+  using acc_t = typename Tr<T>::acc_t;
+  __shared__ SmemP<T> sm;
+  const int tix = blockIdx.x / nbm, rb = blockIdx.x % nbm;
+  T *Arow = tiles + (long)tix * bsiz + rb * MACRO;  // element (m, n) of the row block at Arow[m + n * mb]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i = lane & 15, q = lane >> 4;
+  constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024;  // 1 KiB pieces per operand per K-slice
+  constexpr int EPP = 1024 / (int)sizeof(T);
+  // both operands of a slice: A = rows of this block, columns k0..k0+15; B = rows of Bsrc, same columns
+  auto dma2 = [&](int buf, const T *Asrc, int lda, const T *Bsrc, int ldb, int k0) {
+#pragma unroll
+    for (int p = 0; p < PIECES / 4; ++p) {
+      const int piece = p * 4 + w;
+      const int e = piece * EPP + lane * 2;
+      const int kk = e / MACRO, r = e % MACRO;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(Asrc + r + (size_t)(k0 + kk) * lda),
+          (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(Bsrc + r + (size_t)(k0 + kk) * ldb),
+          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
+    }
+  };
+  auto dma1 = [&](int buf, const T *Bsrc, int ldb, int k0) {
+#pragma unroll
+    for (int p = 0; p < PIECES / 4; ++p) {
+      const int piece = p * 4 + w;
+      const int e = piece * EPP + lane * 2;
+      const int kk = e / MACRO, r = e % MACRO;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(Bsrc + r + (size_t)(k0 + kk) * ldb),
+          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
+    }
+  };
+  const int arow = 32 * w + 2 * i;
+  for (int c = 0; c < nbm; ++c) {
+    acc_t acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+    // ---- S = X[:, 0:128c] L(c, 0:128c)^T
+    if (c > 0) {
+      const T *Bsrc = lkk + c * MACRO;
+      const int nk = c * (MACRO / BK);
+      vec_t fa[2], fb[2][4];
+      auto fread = [&](int set, int cur, int ks) {
+        fa[set] = *reinterpret_cast<const vec_t *>(&sm.a[cur][ks * 4 + q][arow]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fb[set][g] = *reinterpret_cast<const vec_t *>(&sm.b[cur][ks * 4 + q][32 * g + 2 * i]);
+      };
+      dma2(0, Arow, mb, Bsrc, mb, 0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        fread(0, cur, 0);
+        if (kt + 1 < nk) dma2(cur ^ 1, Arow, mb, Bsrc, mb, (kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = Tr<T>::mfma(fb[ks & 1][0][0], fa[ks & 1][0], acc[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < BK / 4) fread((ks + 1) & 1, cur, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+              if (a + b > 0) acc[a][b] = Tr<T>::mfma(fb[ks & 1][b >> 1][b & 1], fa[ks & 1][a], acc[a][b]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+    }
+    // ---- T = A[:, c] - S, in the accumulator layout (two consecutive rows per 16-byte load)
+    // lane ids made opaque per column block: otherwise the 64 per-lane addresses of the loads and
+    // stores below are hoisted out of the c loop (they are loop-invariant up to the block offset), kept
+    // for its whole length and spill the accumulators
+    int q_ = q, i_ = i;
+    asm volatile("" : "+v"(q_), "+v"(i_));
+    const int arow_ = 32 * w + 2 * i_;
+    T *Cb = Arow + (long)c * MACRO * mb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      vec_t av[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          av[e][r] = *reinterpret_cast<const vec_t *>(Cb + arow_ + (long)(32 * g + 8 * r + 2 * q_ + e) * mb);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) acc[a][2 * g + e][r] = av[e][r][a] - acc[a][2 * g + e][r];
+      __builtin_amdgcn_sched_barrier(0);  // one batch of 8 loads in flight: all 32 hoisted together spill the accumulators
+    }
+    // ---- X[:, c] = T Winv_c^T: the operand T comes straight from the accumulator registers
+    const T *Wc = winv + (long)c * MACRO * MACRO;  // column-major, ld = 128: column k = the k-th row of the [k][n'] image
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      acc_t y[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[a][b][r] = T(0);
+      dma1(0, Wc, MACRO, 0);
+      __syncthreads();
+      static_for<0, MACRO / BK>([&](auto S) {
+        constexpr int s = decltype(S)::value, cur = s & 1, g = s >> 1;
+        if constexpr (s + 1 < MACRO / BK) dma1(cur ^ 1, Wc, MACRO, (s + 1) * BK);
+        // the four k-groups of the slice: (r, e), lane (i, q) contributes k = 16 s + 8 (r & 1) + 2 q + e;
+        // W fragments double-buffered one k-group ahead, nothing hoisted across the groups
+        vec_t fw[2][2];
+        auto wread = [&](int set, int st) {
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg)
+            fw[set][gg] = *reinterpret_cast<const vec_t *>(&sm.b[cur][8 * (st >> 1) + 2 * q_ + (st & 1)][64 * h + 32 * gg + 2 * i_]);
+        };
+        wread(0, 0);
+        static_for<0, 4>([&](auto ST) {
+          // every index into the accumulator arrays is a compile-time constant (a run-time index
+          // would put them in scratch)
+          constexpr int st = decltype(ST)::value, r = 2 * (s & 1) + (st >> 1), e = st & 1, bt = 2 * g + e;
+          __builtin_amdgcn_sched_barrier(0);
+          y[0][0] = Tr<T>::mfma(fw[st & 1][0][0], acc[0][bt][r], y[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (st + 1 < 4) wread((st + 1) & 1, st + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if (a + b > 0) y[a][b] = Tr<T>::mfma(fw[st & 1][b >> 1][b & 1], acc[a][bt][r], y[a][b]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+      });
+      // store the 64 columns of this pass (rows 2i, 2i+1 in one 16-byte store)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vec_t v;
+          v[0] = y[0][b][r];
+          v[1] = y[1][b][r];
+          *reinterpret_cast<vec_t *>(Cb + arow_ + (long)(64 * h + 32 * (b >> 1) + 8 * r + 2 * q_ + (b & 1)) * mb) = v;
+        }
+    }
+    // the block just written is an operand of the next column block's K-loop (this workgroup's own
+    // LDS-DMA reads): workgroup-scope release / acquire around a barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 }
 
 // in-tile trailing update of the blocked POTRF: C[r,c] -= X[r,s] X[c,s]^T, r >= c > s
@@ -912,15 +1112,6 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
     }
   }
   __syncthreads();
-}
-
-// compile-time loop (indices usable as constants inside the body)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
 }
 
 // Producer side of phase A: the 16 values of a just-published column as one burst of LDS
@@ -1614,12 +1805,15 @@ int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
+int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield) {
+                         int nb, const PanelRef &pan, bool yield, const PanelRef *pan2) {
   if (na + nb <= 0) return;
+  const int npan = pan2 ? 2 : 1;
+  const PanelRef &p2 = pan2 ? *pan2 : pan;
   offb -= off;  // the kernels index from d_list + off
   const int nbm = C.mb / MACRO, MT = nbm * nbm, MTd = nbm * (nbm + 1) / 2;
   const long tot_a = (long)na * MT, tot_b = (long)nb * MTd;
@@ -1633,10 +1827,10 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
     k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, g_ablate & 255);
   else if (g_variant == 1)
     k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                  yield ? g_ytab : nullptr);
+                                                  yield ? g_ytab : nullptr, p2, npan);
   else
     k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                 yield ? g_ytab : nullptr);
+                                                 yield ? g_ytab : nullptr, p2, npan);
 }
 
 // One 128-column step of the panel TRSM over `ntiles` tiles: X[:, st] = A[:, st] Winv_st^T, then
@@ -1691,15 +1885,34 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
   }
 }
 
+// throughput form of the panel TRSM (fp64, alpha = 1): one launch for all tiles; needs the whole factored
+// diagonal tile and all its block inverses
+template <typename T>
+bool trsm_fused_applies(int ntiles, int mb) {
+  return sizeof(T) == 8 && mb >= 2 * MACRO && g_trsm_fused_min > 0 && ntiles >= g_trsm_fused_min;
+}
+template <typename T>
+void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb) {
+  if constexpr (sizeof(T) == 8) {
+    if (ntiles > 0) k_trsm_fused<T><<<ntiles * (mb / MACRO), 256, 0, s>>>(tiles, bsiz, mb, mb / MACRO, lkk, winv);
+  }
+}
+
 // POTRF of the diagonal tile and TRSM of the panel tiles below it, pipelined over two streams:
 // TRSM step s needs only Winv_s and the blocks L(c,s), c > s, of the diagonal tile, which exist
 // as soon as in-tile step s is done -- so it runs on `st` while the POTRF goes on with step s+1
 // on `sp`.  The chain of a wave shrinks from POTRF + TRSM to about POTRF + one TRSM step.
+// A long panel is solved in the throughput form instead (one launch once the POTRF is complete);
+// only its head tile -- the one the next diagonal tile's SYRK, and with it the next POTRF, waits
+// for -- still follows the POTRF step by step.  ev_head (may be null) is recorded on `st` when the
+// head tile is done.
 // ev: nbm events.  Both streams must be joined by the caller.
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
-                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles) {
+                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head) {
   const int nbm = mb / MACRO;
+  const bool fused = trsm_fused_applies<T>(ntiles - 1, mb);
+  const int nstep = fused ? 1 : ntiles;  // tiles that follow the POTRF step by step
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
     k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
@@ -1713,24 +1926,25 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
     if (ntiles > 0) {
       (void)hipEventRecord(ev[s], sp);
       (void)hipStreamWaitEvent(st, ev[s], 0);
-      trsm_step<T>(st, tiles, bsiz, ntiles, lkk, winv, mb, s, T(1));
+      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
     }
     if (nr > 0) {
-      if (g_intile_small)
-        {
+      if (g_intile_small) {
         T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
         const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
         k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
-      }
-      else
+      } else {
         k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
+      }
     }
   }
+  if (ev_head) (void)hipEventRecord(ev_head, st);
+  if (fused) launch_trsm_fused<T>(st, tiles + bsiz, bsiz, ntiles - 1, lkk, winv, mb);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
-                                             int *, int, double *, long, int);
+                                             int *, int, double *, long, int, hipEvent_t);
 template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
-                                            int, float *, long, int);
+                                            int, float *, long, int, hipEvent_t);
 
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
@@ -1745,6 +1959,10 @@ void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
                        int mb, T alpha) {
   if (ntiles <= 0) return;
   const int nbm = mb / MACRO;
+  if (alpha == T(1) && trsm_fused_applies<T>(ntiles, mb)) {
+    launch_trsm_fused<T>(s, tiles, bsiz, ntiles, lkk, winv, mb);
+    return;
+  }
   // the TRSM of the next panel outranks the trailing update whenever the update yields at all (the
   // walker enables that only while the panel chain is the critical path)
   for (int st = 0; st < nbm; ++st) trsm_step<T>(s, tiles, bsiz, ntiles, lkk, winv, mb, st, alpha);
@@ -1814,7 +2032,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int, int,  \
-                                       int, const PanelRef &, bool);                                \
+                                       int, const PanelRef &, bool, const PanelRef *);              \
   template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int);                       \
   template void launch_diag_syrk<T>(hipStream_t, T *, const T *, int);                               \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
