@@ -123,47 +123,79 @@ def run_single(a) -> dict:
 
 
 def run_multi(a) -> dict:
+    """One process per GPU.  The factorisation is ONE call per step -- CHAMELEON_dpotrf_Tile on the
+    p x q descriptor: the C++ wave loop of libcholmi with its own RCCL communicator (point-to-point
+    groups over xGMI).  torch.distributed (gloo) only bootstraps: it shares the RCCL id, and carries
+    the barriers and the MAX over ranks of the timing.
+    CHOLMI_DIST_BACKEND = rccl (default) | gloo (rehearsal: the same C++ loop, tiles moved by gloo, so
+    that several ranks can share the GPUs that exist) | python (round 1's torch.distributed wave loop)."""
     import torch
     import torch.distributed as dist
 
+    from dense_linear_app_amd import chameleon as ch
     from dense_linear_app_amd import distributed as dd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    # rehearsal hook: CHOLMI_DIST_BACKEND=gloo lets several ranks share the GPUs that exist
-    backend = os.environ.get("CHOLMI_DIST_BACKEND", "nccl")
+    backend = os.environ.get("CHOLMI_DIST_BACKEND", "rccl")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "python":
+        tb = os.environ.get("CHOLMI_TORCH_BACKEND", "nccl")
+        if tb == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(tb)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group("gloo")
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
-    chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
-    chol.warm_up()
-    for w in range(a.warmup):
+    transport = None
+    if backend == "rccl":
+        dd.install_rccl_transport(dist)
+        factor = eng.potrf_tile
+    elif backend == "gloo":
+        transport = dd.TorchTransport(dist, device=local)
+        transport.install()
+        factor = eng.potrf_tile
+    else:
+        chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
+        chol.warm_up()
+        factor = chol.factorize
+    for w in range(max(1, a.warmup)):  # at least one: RCCL connects its peers on first use
         eng.generate(float(a.N), a.seed)
-        info = chol.factorize()
+        info = factor()
         assert info == 0, info
     elapsed = 0.0
-    # the local part is small (N^2/world), but keep one buffer: regenerate between steps,
-    # bracket every step by barrier + synchronize and sum the K bracketed times
+    # regenerate between steps, bracket every step by barrier + synchronize and sum the K bracketed times
     for s in range(a.steps):
         eng.generate(float(a.N), a.seed)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        info = chol.factorize()
+        info = factor()
         torch.cuda.synchronize()
         dist.barrier()
         elapsed += time.perf_counter() - t0
-    assert info == 0, info
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev)
+        assert info == 0, (s, info)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out = {"elapsed": float(t.item()), "rank": rank, "grid": f"{P}x{Q}"}
+    stats = dd.dist_last_stats() if backend != "python" else None
+    # the factor of the last timed step, gathered on rank 0 and checked (untimed) against the regenerated matrix
+    res = None
+    if not a.no_check and backend != "python":
+        full = None
+        if rank == 0:
+            dt = ch.ChamRealDouble if a.dtype == "f64" else ch.ChamRealFloat
+            full = ch.CHAMELEON_Desc_Create(None, dt, a.tile, a.tile, a.tile * a.tile, a.N, a.N, 0, 0, a.N, a.N, 1, 1)
+        dd.gather_lower(eng.desc, full, 0)
+        if rank == 0:
+            res = ch.residual_plgsy(full, float(a.N), a.seed)
+            ch.CHAMELEON_Desc_Destroy(full)
+    out = {"elapsed": float(t.item()), "rank": rank, "grid": f"{P}x{Q}", "residual": res, "dist": stats,
+           "backend": backend}
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -208,10 +240,13 @@ def main() -> int:
                 "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
                 "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
             }
-        if r.get("residual") is not None:
-            line["residual"] = r["residual"]
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
+    if r.get("residual") is not None:
+        line["residual"] = r["residual"]
+    if r.get("dist"):
+        line["config"]["exchange"] = {"backend": r["backend"], "host_issue_us_per_wave": round(r["dist"]["issue_us_per_wave"], 1),
+                                      "sends_per_rank0": r["dist"]["sends"], "bytes_sent_rank0": r["dist"]["bytes_sent"]}
     print(json.dumps(line), flush=True)
     return 0
 

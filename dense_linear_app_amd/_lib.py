@@ -79,6 +79,13 @@ def lib() -> C.CDLL:
         "chol_wave_update_diag": ([vp, i, i, pp, C.POINTER(i), vp], i),
         "chol_get_info": ([C.POINTER(i)], i),
         "chol_reset_info": ([], i),
+        "chol_set_transport": ([vp], i),
+        "chol_transport_rccl_unique_id": ([vp], i),
+        "chol_transport_rccl_init": ([vp, i, i], i),
+        "chol_transport_rccl_finalize": ([], i),
+        "chol_dist_last_stats": ([C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i),
+        "chol_dist_factorize_with": ([vp, vp, i, i, i, i, i, i], i),
+        "chol_dist_gather_lower": ([vp, vp, i], i),
     }
     for name, (argt, rest) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -19,24 +19,8 @@
 
 using namespace cholmi;
 
-struct chol_desc {
-  int dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q;
-  int mbi, bsizi;    // stored tile edge / size: mb rounded up to 128 when the library owns a padded image
-  bool padded;       // stored tiles are larger than (mb, nb) and/or the last tile row/column is ragged
-  int mt, nt;        // global tile grid
-  int prow, pcol;    // this process's grid coordinates
-  int lmt, lnt;      // local tile grid
-  size_t esize;
-  void *mat;         // storage as seen by the caller (host or device)
-  bool on_device;    // mat is device memory
-  bool owns;         // library allocated mat
-  // static work list of the trailing updates: the local strictly-lower tiles sorted by column
-  // descending (rows ascending inside a column), entries with column >= j in [0, ge[j]); then,
-  // from n_off on, the local diagonal tiles sorted by column descending, [n_off, n_off + gd[j])
-  int2 *d_list = nullptr;
-  std::vector<int> ge, gd;
-  int n_off = 0;
-};
+extern "C" int chol_internal_dist_potrf(chol_desc *d, int rank);  // dist.hip
+extern "C" void chol_internal_dist_finalize(void);
 
 namespace {
 
@@ -488,9 +472,7 @@ static int potrf_impl(chol_desc *A) {
     rc = read_info(&info);
     return rc ? rc : info;
   }
-  if (A->p * A->q != 1)
-    return fail(CHOL_ERR_NOT_SUPPORTED,
-                "potrf_tile on a distributed descriptor: use the chol_wave_* building blocks");
+  if (A->p * A->q != 1) return chol_internal_dist_potrf(A, g.rank);  // dist.hip: the block-cyclic wave loop
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
   if (A->on_device) return potrf_full_device<T>(A, A->mat);
   // host-resident tiled matrix: stage the whole matrix through HBM
@@ -612,7 +594,9 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
 
 extern "C" {
 
-const char *chol_version(void) { return "cholmi 0.1 (gfx950)"; }
+int chol_internal_fail(int code, const char *msg) { return fail(code, msg); }
+
+const char *chol_version(void) { return "cholmi 0.2 (gfx950)"; }
 const char *chol_last_error(void) { return g.last_error.c_str(); }
 
 int chol_set_device(int device) {
@@ -681,6 +665,7 @@ int chol_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.inited) return 0;
   (void)hipDeviceSynchronize();
+  chol_internal_dist_finalize();
   for (auto e : g.events) (void)hipEventDestroy(e);
   g.events.clear();
   for (int i = 0; i < 3; ++i) {

@@ -6,6 +6,29 @@
 #include <algorithm>
 #include <vector>
 
+#include "../../include/cholmi.h"
+
+// The descriptor behind chol_desc_t (include/cholmi.h): Chameleon's CHAM_desc_t arguments plus what
+// this library derives from them.
+struct chol_desc {
+  int dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q;
+  int mbi, bsizi;    // stored tile edge / size: mb rounded up to 128 when the library owns a padded image
+  bool padded;       // stored tiles are larger than (mb, nb) and/or the last tile row/column is ragged
+  int mt, nt;        // global tile grid
+  int prow, pcol;    // this process's grid coordinates
+  int lmt, lnt;      // local tile grid
+  size_t esize;
+  void *mat;         // storage as seen by the caller (host or device)
+  bool on_device;    // mat is device memory
+  bool owns;         // library allocated mat
+  // static work list of the trailing updates: the local strictly-lower tiles sorted by column
+  // descending (rows ascending inside a column), entries with column >= j in [0, ge[j]); then,
+  // from n_off on, the local diagonal tiles sorted by column descending, [n_off, n_off + gd[j])
+  int2 *d_list = nullptr;
+  std::vector<int> ge, gd;
+  int n_off = 0;
+};
+
 namespace cholmi {
 
 constexpr int MACRO = 128;  // macro-tile edge: one workgroup's C block, and the

@@ -565,6 +565,136 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
     nt_epilogue_paired_impl<T, false>(Cp, C.mb, acc, T(-1), T(1));
 }
 
+// ------------------------------------------------------------------------------
+// The same trailing update with EIGHT waves per workgroup (fp64): 2 x 4 waves, each 64 rows x 32
+// columns of the 128 x 128 block, two workgroups per CU = four waves per SIMD instead of two.  Every
+// wave still stalls once per K-slice (fragment read after the barrier, the barrier itself, the DMA
+// issue); with four independent MFMA streams per SIMD the matrix pipe finds a ready wave more often.
+// Costs: 3 fragment reads per 8 MFMAs instead of 4 per 16, and <= 128 VGPRs per wave.
+// ------------------------------------------------------------------------------
+// MODE bit 0: the next slice's DMA is issued behind the first MFMAs of k-groups 0 and 1 instead of
+// in one burst between the barrier and the slice's first MFMA; bit 1: static priority 1 for waves 4-7
+template <typename T, int MODE>
+__device__ __forceinline__ void nt_kloop_w8(const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb,
+                                            int K, typename Tr<T>::acc_t (&acc)[4][2], SmemP<T> &sm,
+                                            const int *yslot) {
+  static_assert(sizeof(T) == 8, "fp64 only");
+  using vec_t = typename Tr<T>::vec_t;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024, EPP = 1024 / (int)sizeof(T);
+  auto dma_piece = [&](int buf, int k0, int p) {
+    const int piece = p * 8 + w;
+    const int e = piece * EPP + lane * 2;
+    const int kk = e / MACRO, r = e % MACRO;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
+        (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+        (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
+  };
+  auto dma = [&](int buf, int k0) {
+#pragma unroll
+    for (int p = 0; p < PIECES / 8; ++p) dma_piece(buf, k0, p);
+  };
+  static_assert(PIECES / 8 == 2, "two pieces per operand per wave and slice");
+  vec_t fa[2][2], fb[2];
+  const int arow = wr * 64 + 2 * i, brow = wc * 32 + 2 * i;
+  if (MODE & 2) {
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+  }
+  auto fread = [&](int set, int cur, int ks) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) fa[set][g] = *reinterpret_cast<const vec_t *>(&sm.a[cur][ks * 4 + q][arow + 32 * g]);
+    fb[set] = *reinterpret_cast<const vec_t *>(&sm.b[cur][ks * 4 + q][brow]);
+  };
+  dma(0, 0);
+  __syncthreads();
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    int guest = 0;
+    if (yslot) guest = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fread(0, cur, 0);
+    if (!(MODE & 1) && kt + 1 < nk) dma(cur ^ 1, (kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = Tr<T>::mfma(fb[ks & 1][0], fa[ks & 1][0][0], acc[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < BK / 4) fread((ks + 1) & 1, cur, ks + 1);
+      if ((MODE & 1) && ks < 2 && kt + 1 < nk) dma_piece(cur ^ 1, (kt + 1) * BK, ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (a + b > 0) acc[a][b] = Tr<T>::mfma(fb[ks & 1][b], fa[ks & 1][a >> 1][a & 1], acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (yslot && __builtin_amdgcn_readfirstlane(guest) != 0) yield_to_guest(yslot);
+    __syncthreads();
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const int2 *__restrict__ list, int na,
+                                                             int offb, int nb, int blocks_a, PanelRef pan, int nbm,
+                                                             int unit, const int *ytab, PanelRef pan2, int npan) {
+  using vec_t = typename Tr<T>::vec_t;
+  __shared__ SmemP<T> sm;
+  BlockMap bm;
+  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
+  const int2 ij = bm.ij;
+  const int mi = bm.mi, mj = bm.mj;
+  const bool lower = (ij.x == ij.y) && mi == mj;
+  T *Cp = reinterpret_cast<T *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
+          mi * MACRO + (long)mj * MACRO * C.mb;
+  typename Tr<T>::acc_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
+  nt_kloop_w8<T, MODE>(panel_tile<T>(pan, ij.x, C.bsiz) + mi * MACRO, C.mb, panel_tile<T>(pan, ij.y, C.bsiz) + mj * MACRO,
+                 C.mb, C.mb, acc, sm, yslot);
+  if (npan > 1)
+    nt_kloop_w8<T, MODE>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
+                   panel_tile<T>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
+  // C -= acc: lane (i, q) holds rows 2i, 2i+1 (+32g) of column 32 wc + 2 (q + 4r) + b
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  const int m0 = wr * 64 + 2 * i;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    vec_t cv[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        cv[r][g] = *reinterpret_cast<const vec_t *>(Cp + (long)(wc * 32 + 2 * (q + 4 * r) + b) * C.mb + m0 + 32 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 32 + 2 * (q + 4 * r) + b;
+      T *col = Cp + (long)n * C.mb;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int m = m0 + 32 * g;
+        vec_t v = cv[r][g];
+        v[0] -= acc[2 * g][b][r];
+        v[1] -= acc[2 * g + 1][b][r];
+        if (!lower || m >= n) {
+          *reinterpret_cast<vec_t *>(col + m) = v;
+        } else {
+          if (m + 1 >= n) col[m + 1] = v[1];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // X[:, s] := alpha * A[:, s] * Winv_s^T, in place, for row blocks r >= r0 of `ntiles`
 // contiguous tiles.  (TRSM by multiplication with the inverted 128x128 diagonal block.)
 template <typename T>
@@ -1825,7 +1955,19 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   const dim3 grid((unsigned)(blocks_a + blocks_b)), blk(256);
   if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
     k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, g_ablate & 255);
-  else if (g_variant == 1)
+  else if (g_variant >= 2 && sizeof(T) == 8) {
+    if constexpr (sizeof(T) == 8) {
+#define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
+                                                     yield ? g_ytab : nullptr, p2, npan)
+      switch (g_variant - 2) {
+        case 1: W8(1); break;
+        case 2: W8(2); break;
+        case 3: W8(3); break;
+        default: W8(0); break;
+      }
+#undef W8
+    }
+  } else if (g_variant == 1)
     k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                   yield ? g_ytab : nullptr, p2, npan);
   else

@@ -180,8 +180,151 @@ class HipEngine:
         self._check("chol_get_info", self._lib.chol_get_info(C.byref(v)))
         return v.value
 
+    def potrf_tile(self) -> int:
+        """CHAMELEON_dpotrf_Tile(ChamLower, desc) on the p x q descriptor: the whole distributed
+        factorisation inside the library (needs an installed transport when p*q > 1)."""
+        return self.ch.CHAMELEON_dpotrf_Tile(self.ch.ChamLower, self.desc)
+
     def destroy(self) -> None:
         self.ch.CHAMELEON_Desc_Destroy(self.desc)
+
+
+# ------------------------------------------------------------------------------------------
+# The distributed factorisation behind the C ABI: chol_potrf_tile on a p x q descriptor runs the
+# wave loop in C++ (csrc/dist.hip) and moves tiles through a transport table (include/cholmi.h,
+# chol_transport_t).  Real runs: the RCCL transport (install_rccl_transport: point-to-point
+# ncclSend / ncclRecv in groups over xGMI).  Tests and one-GPU rehearsals: TorchTransport, the same
+# table filled with torch.distributed point-to-point calls (gloo).
+# ------------------------------------------------------------------------------------------
+class _TransportTable(C.Structure):
+    _fields_ = [("ctx", C.c_void_p),
+                ("group_begin", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("send", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)),
+                ("recv", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)),
+                ("group_end", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("allreduce_max", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_longlong)))]
+
+
+class _DevPtr:
+    """Raw device memory as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class TorchTransport:
+    """chol_transport_t over torch.distributed point-to-point operations (any backend).
+
+    device=None: the buffers are host memory (the CPU tests of the wave loop);
+    device=n: HBM of cuda:n -- the stream the library names is drained before a group moves, since
+    gloo knows nothing of HIP streams.  One group = all isend / irecv posted, then all waited for."""
+
+    def __init__(self, dist, device: Optional[int] = None):
+        import torch
+
+        self.dist, self.torch, self.device = dist, torch, device
+        self.ops: List = []
+        self.keep: List = []
+        self.nbytes = 0
+        T = _TransportTable
+        self.table = T(None, T._fields_[1][1](self._begin), T._fields_[2][1](self._send), T._fields_[3][1](self._recv),
+                       T._fields_[4][1](self._end), T._fields_[5][1](self._allreduce_max))
+
+    def _view(self, ptr: int, nbytes: int):
+        if self.device is None:
+            buf = (C.c_char * nbytes).from_address(ptr)
+            return self.torch.frombuffer(buf, dtype=self.torch.uint8)
+        return self.torch.as_tensor(_DevPtr(ptr, nbytes), device=f"cuda:{self.device}")
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import traceback
+
+            traceback.print_exc()
+            self.error = e
+            return -103
+
+    def _begin(self, ctx):
+        self.ops, self.keep = [], []
+        return 0
+
+    def _send(self, ctx, buf, nbytes, peer, stream):
+        def f():
+            t = self._view(buf, nbytes)
+            self.keep.append(t)
+            self.ops.append(("s", t, peer))
+            self.nbytes += nbytes
+        return self._guard(f)
+
+    def _recv(self, ctx, buf, nbytes, peer, stream):
+        def f():
+            t = self._view(buf, nbytes)
+            self.keep.append(t)
+            self.ops.append(("r", t, peer))
+        return self._guard(f)
+
+    def _end(self, ctx):
+        def f():
+            if self.device is not None:
+                self.torch.cuda.synchronize(self.device)
+            reqs = [self.dist.isend(t, peer) if kind == "s" else self.dist.irecv(t, peer) for kind, t, peer in self.ops]
+            for r in reqs:
+                r.wait()
+            if self.device is not None:
+                self.torch.cuda.synchronize(self.device)
+            self.ops, self.keep = [], []
+        return self._guard(f)
+
+    def _allreduce_max(self, ctx, value):
+        def f():
+            t = self.torch.tensor([value[0]], dtype=self.torch.int64)
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            value[0] = int(t.item())
+        return self._guard(f)
+
+    def install(self) -> None:
+        from ._lib import check, lib
+
+        check("chol_set_transport", lib().chol_set_transport(C.byref(self.table)))
+
+
+def install_rccl_transport(dist) -> None:
+    """Build the library's own RCCL communicator: rank 0 creates the id, torch.distributed (any
+    backend; only its object broadcast is used) shares it, every rank joins."""
+    from ._lib import check, lib
+
+    L = lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        check("chol_transport_rccl_unique_id", L.chol_transport_rccl_unique_id(buf))
+    box = [bytes(buf)]
+    dist.broadcast_object_list(box, src=0)
+    ident = (C.c_char * 128).from_buffer_copy(box[0])
+    check("chol_transport_rccl_init", L.chol_transport_rccl_init(ident, rank, world))
+
+
+def gather_lower(src_desc, dst_desc, root: int = 0) -> None:
+    """Every rank: send the lower tiles of the p x q descriptor to `root`'s single-process descriptor
+    (dst_desc is None elsewhere)."""
+    from ._lib import check, lib
+
+    check("chol_dist_gather_lower",
+          lib().chol_dist_gather_lower(src_desc.handle, dst_desc.handle if dst_desc is not None else None, root))
+
+
+def dist_last_stats() -> dict:
+    from ._lib import lib
+
+    us = C.c_double()
+    a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    lib().chol_dist_last_stats(C.byref(us), C.byref(a), C.byref(b), C.byref(c))
+    return {"issue_us_per_wave": us.value, "sends": a.value, "recvs": b.value, "bytes_sent": c.value}
 
 
 class BlockCyclicCholesky:

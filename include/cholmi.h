@@ -94,8 +94,9 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
 int chol_desc_destroy(chol_desc_t **desc);
 
 /* CHAMELEON_dpotrf_Tile(uplo, A) W2:238, V6:56 (spotrf by descriptor dtype).
- * Works on a 1-tile descriptor (worker path) and on a whole tiled matrix (driver path: the
- * full wave DAG of C2:506-565 runs on the device).  ChamUpper is served for device-resident
+ * Works on a 1-tile descriptor (worker path), on a whole tiled matrix (driver path: the full wave
+ * DAG of C2:506-565 runs on the device) and on a p x q block-cyclic descriptor (one process per GPU,
+ * ChamLower; needs a transport, see chol_set_transport below).  ChamUpper is served for device-resident
  * matrices by transposing the storage in place around the Lower factorisation (the strict
  * lower triangle is returned untouched). */
 int chol_potrf_tile(int uplo, chol_desc_t *A);
@@ -222,6 +223,64 @@ int chol_wave_update_diag(chol_desc_t *desc, int k, int j, const void *const *pa
                           const int *panel_first, void *stream);
 int chol_get_info(int *info); /* device-side POTRF status word of the current factorisation */
 int chol_reset_info(void);
+
+/* ---- distributed factorisation behind chol_potrf_tile --------------------- */
+/* chol_potrf_tile(ChamLower, A) on a descriptor with p*q > 1 (the reference passes p, q from argv
+ * straight into CHAMELEON_Desc_Create, V6:26-27, 44-45) runs the 2D block-cyclic wave DAG of all
+ * p*q processes inside the library: the wave loop is C++ (no per-wave host-language code), the tiles
+ * move through the transport installed below.  Per wave: L(k,k) (with its block inverses) goes from
+ * its owner to the other ranks of its process column; every panel tile L(i,k) goes along process
+ * row i mod p (whole contiguous parts) and to the ranks of process column i mod q (tile by tile) --
+ * point to point, one group per wave; nobody receives a tile it does not use.
+ *
+ * A transport is a table of stream-ordered point-to-point operations.  `stream` is a hipStream_t;
+ * everything issued between group_begin and group_end progresses together (ncclGroupStart /
+ * ncclGroupEnd semantics: sends and receives of one group may be matched in any order).
+ * allreduce_max is a blocking host-value reduction (the final LAPACK info). */
+typedef struct chol_transport {
+  void *ctx;
+  int (*group_begin)(void *ctx);
+  int (*send)(void *ctx, const void *buf, size_t bytes, int peer, void *stream);
+  int (*recv)(void *ctx, void *buf, size_t bytes, int peer, void *stream);
+  int (*group_end)(void *ctx);
+  int (*allreduce_max)(void *ctx, long long *value);
+} chol_transport_t;
+/* Install (copy) a transport; NULL removes it.  Ranks are those of chol_set_rank. */
+int chol_set_transport(const chol_transport_t *t);
+/* The RCCL transport (xGMI inside a node): rank 0 creates the 128-byte id, the application shares it
+ * out of band (MPI, torch.distributed store, a file), every rank calls _init -- which builds the
+ * communicator on this process's device and installs the transport (ncclSend / ncclRecv in
+ * ncclGroupStart / ncclGroupEnd).  librccl is loaded at this call, not at link time. */
+int chol_transport_rccl_unique_id(void *id128);
+int chol_transport_rccl_init(const void *id128, int rank, int nranks);
+int chol_transport_rccl_finalize(void);
+/* Host time spent issuing the last distributed factorisation (everything but the final
+ * synchronisation), in microseconds per wave, and the number of transport operations it posted. */
+int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long *recvs, long long *bytes_sent);
+
+/* Collect the lower tiles of a p x q descriptor on rank `root` into a device-resident single-process
+ * descriptor of the same order, tile size and type (`dst` is ignored on the other ranks): lets the
+ * root verify a distributed factorisation with chol_residual_plgsy.  Collective over the p*q ranks. */
+int chol_dist_gather_lower(chol_desc_t *src, chol_desc_t *dst, int root);
+
+/* Test hook: the same C++ wave loop over caller-supplied tile kernels, so that the distribution
+ * logic (ownership, addressing, matching of sends and receives, buffer reuse) can run without a
+ * GPU under any transport.  NOT a compute path of the product: chol_potrf_tile never uses it.
+ * Tiles are addressed as in a descriptor: local tile (il, jl) of an lmt x lnt local grid at
+ * store + (il + jl*lmt) * B*B elements.  All callbacks are synchronous. */
+typedef struct chol_test_engine {
+  void *ctx;
+  void *store;      /* this rank's tiles */
+  size_t esize;     /* bytes per element */
+  void *(*alloc)(void *ctx, size_t bytes);                       /* receive buffers */
+  int (*potrf)(void *ctx, int k, void *lkk);
+  int (*trsm)(void *ctx, int k, const void *lkk);
+  int (*update)(void *ctx, int k, int jlo, int jhi, const void *const *bases, const int *firsts, int skip_diag);
+  int (*update_diag)(void *ctx, int k, int j, const void *const *bases, const int *firsts);
+  int (*info)(void *ctx);
+} chol_test_engine_t;
+int chol_dist_factorize_with(const chol_test_engine_t *engine, const chol_transport_t *transport, int N, int B,
+                             int p, int q, int rank, int lookahead);
 
 #ifdef __cplusplus
 }
