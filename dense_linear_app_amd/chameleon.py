@@ -76,6 +76,9 @@ class Desc:
               lib().chol_desc_create(C.byref(h), addr, dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q))
         self._h = h
         self.dtype, self.mb, self.nb, self.bsiz = dtype, mb, nb, bsiz
+        if (i, j, m, n) != (0, 0, lm, ln):
+            # a sub-matrix view (library-owned storage): everything below works in view coordinates
+            lm, ln = m, n
         self.lm, self.ln, self.m, self.n, self.p, self.q = lm, ln, m, n, p, q
         self.mt, self.nt = (lm + mb - 1) // mb, (ln + nb - 1) // nb
 

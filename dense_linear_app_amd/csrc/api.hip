@@ -456,15 +456,20 @@ int build_worklist(chol_desc *d) {
 }
 
 template <typename T>
-static int potrf_impl(chol_desc *A) {
+static int potrf_impl(chol_desc *A, bool upper_staged = false) {
   CHECK_WINV(A, "potrf_tile");
   if (single_tile_square(A)) {
     Staged st;
     int rc = stage_in<T>(A, 0, /*identity_pad=*/true, &st);
     if (rc) return rc;
     HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
+    // ChamUpper on a staged tile: A = U^T U with U = L^T -- transpose the staged (identity-padded,
+    // multiple-of-128) copy, factor Lower, transpose back: the caller's strict lower triangle comes
+    // back exactly as it went in
+    if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
     launch_potrf_tile<T>(g.s_main, reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.winv),
                          g.d_info, 0);
+    if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
     rc = stage_out<T>(A, st);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(g.s_main));
@@ -708,8 +713,20 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
   if (p <= 0 || p > MAXP) return fail(-13, "desc_create: p");
   if (q <= 0) return fail(-14, "desc_create: q");
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "desc_create before chol_init");
-  if (i != 0 || j != 0 || m != lm || n != ln)
-    return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views (i,j,m,n) are not supported");
+  if (i != 0 || j != 0 || m != lm || n != ln) {
+    // A sub-matrix view A(i:i+m, j:j+n) of an lm x ln matrix (V6:24-25, 44-45 pass ioff, joff, m, n
+    // straight through).  With library-owned storage nothing outside the view can ever be observed
+    // through this descriptor -- Chameleon's generator, factorisation and layout conversions all work in
+    // view coordinates (dplgsy: entry (r, c) of the view, order m) -- so the view IS an m x n matrix of
+    // its own: only the tiles it can address are allocated.  Tile-aligned offsets only (an unaligned
+    // view starts with a partial tile, which would change what tile (0,0) means to tile_upload / _download).
+    if (mat) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views (i,j,m,n) over a user buffer are not supported");
+    if (i % mb || j % nb) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views need tile-aligned offsets (i % mb == 0, j % nb == 0)");
+    if (p * q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views of distributed matrices are not supported");
+    lm = m;
+    ln = n;
+    i = j = 0;
+  }
   if (p * q != 1 && p * q != g.nranks)
     return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: p*q must equal the number of ranks (chol_set_rank)");
   chol_desc *d = new chol_desc();
@@ -820,7 +837,7 @@ int chol_potrf_tile(int uplo, chol_desc_t *A) {
   if (!one && (A->p * A->q != 1 || !A->on_device || A->mt != A->nt))
     return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile(Upper): single-process device-resident square matrices");
   if (one && !(A->on_device && A->mb % MACRO == 0))
-    return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile(Upper) on a staged 1-tile descriptor");
+    return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A, true) : potrf_impl<float>(A, true);
   auto flip = [&]() {
     if (A->dtype == CHOL_REAL_DOUBLE)
       launch_transpose_inplace<double>(g.s_main, (double *)A->mat, A->nt, A->mbi);

@@ -1931,7 +1931,7 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU hand-over), may be null
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
-int g_variant = 0;  // 0: LDS-DMA staging (default); 1: register staging (CHOLMI_VARIANT)
+int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four waves + register staging, 2..5 eight waves (MODE = variant - 2: bit 0 DMA behind the first MFMAs, bit 1 static priority); fp32 always 0 / 1 (CHOLMI_VARIANT)
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)

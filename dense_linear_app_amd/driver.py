@@ -8,6 +8,7 @@ and benchmark.c ("BN"):
                             dplgsy_Tile(bump=N, seed) -> timed dpotrf_Tile -> "Performance: %.2f
                             Gflop/s" with N^3/3 flops (V6:60) -> validation -> cleanup; exit code
                             = (info != 0) (V6:95)
+  v3_test(argv)   v3:69-238  the long-option driver (--dtyp d|s, --uplo L|U, --bump, --mat none|user, offsets)
   bench(...)      BN:103, 201, 282-285   1 warm-up ("calibration") + 7 timed repeats per (N, NB),
                             CSV columns timestamp,scheduler,mapping,ncpu,ngpu,N,NB,run_idx,ms,
                             exit_code,gflops,rel_error (+ tflops,pct_peak,dtype)
@@ -168,8 +169,125 @@ def bench(Ns: Sequence[int], NBs: Sequence[int], csv_path: Optional[str] = None,
     return rows
 
 
+V3_OPTIONS = ("N", "NB", "ncpu", "ngpu", "mat", "dtyp", "mb", "nb", "bsiz", "lm", "ln", "i", "j", "m", "n", "p", "q",
+              "bump", "uplo", "seed")
+
+V3_USAGE = ("Usage: %s --N INT --NB INT --ncpu INT --ngpu INT --mat none|user --dtyp d|s|z|c \\\n"
+            "          --mb INT --nb INT --bsiz INT --lm INT --ln INT --i INT --j INT \\\n"
+            "          --m INT --n INT --p INT --q INT --bump DOUBLE --uplo L|U|B --seed ULL\n\n"
+            "ALL options are required. No defaults.\n")
+
+
+def v3_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr) -> int:
+    """The reference's long-option driver, Cholesky_Chameleon_sauv/code_c/v3_script_cholesky_x_arg_gpt.c:
+    every option required (v3:122-127), --dtyp d|s|z|c and --uplo L|U|B mapped as v3:25-45, the checks of
+    v3:174-195, then Init -> Desc_Create -> dplgsy(bump, uplo, seed) -> timed dpotrf(uplo) -> the three
+    output lines of v3:229-232; exit code = (info != 0).  `argv` excludes the program name.
+    --mat user allocates an lm x ln host buffer for the descriptor (v3:156-172): tiles are then staged
+    through HBM around the call.  z / c (complex) are valid Chameleon types this library does not carry."""
+    import numpy as np
+
+    vals: dict = {}
+    k = 0
+    argv = list(argv)
+    while k < len(argv):
+        a = argv[k]
+        if a in ("-h", "--help"):
+            err.write(V3_USAGE % "v3_test")
+            return 0
+        name = a[2:] if a.startswith("--") else None
+        if name and "=" in name:
+            name, v = name.split("=", 1)
+            k += 1
+        elif name and k + 1 < len(argv):
+            v = argv[k + 1]
+            k += 2
+        else:
+            err.write(V3_USAGE % "v3_test")
+            return 1
+        if name not in V3_OPTIONS:
+            err.write(V3_USAGE % "v3_test")
+            return 1
+        vals[name] = v
+    if any(o not in vals for o in V3_OPTIONS):
+        err.write("Error: all options are required. Missing at least one.\n")
+        err.write(V3_USAGE % "v3_test")
+        return 1
+    N, NB, ncpu, ngpu, mb, nb, lm, ln, ioff, joff, m, n, p, q = (
+        _atoi(vals[o]) for o in ("N", "NB", "ncpu", "ngpu", "mb", "nb", "lm", "ln", "i", "j", "m", "n", "p", "q"))
+    bsiz = _atoi(vals["bsiz"])
+    try:
+        bump = float(vals["bump"])
+    except ValueError:
+        bump = 0.0
+    seed = _atoi(vals["seed"]) & 0xFFFFFFFFFFFFFFFF
+    dtyp = {"d": ch.ChamRealDouble, "D": ch.ChamRealDouble, "0": ch.ChamRealDouble,
+            "s": ch.ChamRealFloat, "S": ch.ChamRealFloat, "1": ch.ChamRealFloat,
+            "z": "z", "Z": "z", "2": "z", "c": "c", "C": "c", "3": "c"}.get(vals["dtyp"])
+    uplo = {"L": ch.ChamLower, "l": ch.ChamLower, "0": ch.ChamLower, "U": ch.ChamUpper, "u": ch.ChamUpper,
+            "1": ch.ChamUpper, "B": ch.ChamUpperLower, "b": ch.ChamUpperLower, "2": ch.ChamUpperLower}.get(vals["uplo"])
+    if dtyp is None:
+        err.write(f"Error: invalid --dtyp {vals['dtyp']}\n")
+        return 1
+    if uplo is None:
+        err.write(f"Error: invalid --uplo {vals['uplo']}\n")
+        return 1
+    if dtyp in ("z", "c"):
+        err.write("Error: --dtyp z|c (complex) is not supported by this library\n")
+        return 1
+    if min(N, NB, mb, nb, lm, ln, m, n, p, q) <= 0:
+        err.write("Error: dimension arguments must be >0.\n")
+        return 1
+    if bsiz < mb * nb:
+        err.write(f"Error: --bsiz < mb*nb (bsiz={bsiz} mb={mb} nb={nb}).\n")
+        return 1
+    if ioff < 0 or joff < 0 or ioff >= lm or joff >= ln:
+        err.write(f"Error: invalid offsets i={ioff} j={joff} (lm={lm} ln={ln}).\n")
+        return 1
+    if ioff + m > lm or joff + n > ln:
+        err.write(f"Error: submatrix (i={ioff},m={m}) outside lm={lm} OR (j={joff},n={n}) outside ln={ln}.\n")
+        return 1
+    if bump == 0.0:
+        err.write("Warning: bump==0 -> matrix may not be SPD.\n")
+    mat = None
+    if vals["mat"] not in ("none", "NULL", "0"):
+        mat = np.zeros(lm * ln, dtype=np.float64 if dtyp == ch.ChamRealDouble else np.float32)
+    ch.CHAMELEON_Init(ncpu, ngpu)
+    try:
+        descA = ch.CHAMELEON_Desc_Create(mat, dtyp, mb, nb, mb * nb, lm, ln, ioff, joff, m, n, p, q)
+        if mat is None:
+            ch.CHAMELEON_dplgsy_Tile(bump, uplo, descA, seed)
+        else:  # the generator runs on the device: fill a resident twin, bring the tiles to the host buffer
+            twin = ch.CHAMELEON_Desc_Create(None, dtyp, mb, nb, mb * nb, lm, ln, ioff, joff, m, n, p, q)
+            ch.CHAMELEON_dplgsy_Tile(bump, uplo, twin, seed)
+            tiles = mat.reshape((twin.mt * twin.nt, mb * nb))
+            for J in range(twin.nt):
+                for I in range(twin.mt):
+                    tiles[I + J * twin.mt, :] = twin.download_tile(I, J).ravel(order="F")
+            ch.CHAMELEON_Desc_Destroy(twin)
+        t0 = time.perf_counter()
+        info = ch.CHAMELEON_dpotrf_Tile(uplo, descA)
+        time_sec = time.perf_counter() - t0
+    except ch.CholmiError as e:
+        err.write(f"Error: {e}\n")
+        return 1
+    dim = float(min(m, n))
+    gflops = (1.0 / 3.0) * dim ** 3 / (time_sec * 1e9)
+    print(f"N={N} NB={NB} ncpu={ncpu} ngpu={ngpu} p={p} q={q} bump={bump:g} uplo={uplo} seed={seed}", file=out)
+    print(f"Time: {time_sec:.6f} s", file=out)
+    print(f"Performance: {gflops:.2f} Gflop/s", file=out)
+    if info != 0:
+        err.write(f"Erreur dans CHAMELEON_dpotrf_Tile: {info}\n")
+    ch.CHAMELEON_Desc_Destroy(descA)
+    return int(info != 0)
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
-    return v6_test(sys.argv[1:] if argv is None else argv)
+    """Positional arguments: v6_test (V6); long options (--N ... --seed): the v3 driver."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if argv and argv[0].startswith("--"):
+        return v3_test(argv)
+    return v6_test(argv)
 
 
 if __name__ == "__main__":

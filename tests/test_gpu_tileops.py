@@ -145,8 +145,6 @@ def test_alpha_beta_and_flags(cham, orc):
     with pytest.raises(ch.CholmiError):
         ch.CHAMELEON_dtrsm_Tile(ch.ChamLeft, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, desc1(ch, Lm), desc1(ch, X))
     with pytest.raises(ch.CholmiError):
-        ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, desc1(ch, X))  # Upper on a staged host tile: not covered
-    with pytest.raises(ch.CholmiError):
         ch.CHAMELEON_dgemm_Tile(ch.ChamTrans, ch.ChamTrans, 1.0, desc1(ch, A), desc1(ch, Bm), 0.0, desc1(ch, Cn))
 
 
@@ -180,3 +178,23 @@ def test_device_resident_tile(cham, orc):
     L = t.cpu().numpy().T
     Lref, _ = orc.dpotrf(Akk)
     assert np.abs(np.tril(L) - np.tril(Lref)).max() <= tol(B, Lref)
+
+
+@pytest.mark.parametrize("B", [12, 200, 256])
+def test_potrf_upper_on_a_staged_host_tile(cham, orc, B):
+    """ChamUpper on the worker's kind of tile (host buffer, any size): A = U^T U in the upper triangle,
+    the strict lower triangle comes back untouched (v3 driver's --uplo U)."""
+    ch = cham
+    rng = np.random.default_rng(B)
+    M = rng.uniform(-1, 1, (B, B))
+    S = M @ M.T + B * np.eye(B)
+    A = np.asfortranarray(np.triu(S) + np.tril(rng.uniform(-9, 9, (B, B)), -1))  # junk below the diagonal
+    got = A.copy(order="F")
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, desc1(ch, got)) == 0
+    Lref, info = orc.dpotrf(np.asfortranarray(S))
+    assert info == 0
+    assert np.abs(np.triu(got) - np.tril(Lref).T).max() <= tol(B, Lref)
+    assert np.array_equal(np.tril(got, -1), np.tril(A, -1))
+    bad = A.copy(order="F")
+    bad[B // 2, B // 2] = -1.0
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, desc1(ch, bad)) == B // 2 + 1
