@@ -232,7 +232,7 @@ def main() -> int:
             ach = r["upd_flops"] / (r["upd_ms"] * 1e-3) / 1e12
             traffic = load_pmc_traffic()
             line["roofline"] = {
-                "bound": "mfma", "kernel": "k_trail_update", "achieved": round(ach, 3), "peak": peak,
+                "bound": "mfma", "kernel": "k_trail_update_w8<double,3>" if a.dtype == "f64" else "k_trail_update<float,true>", "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # PMC pass = one factorisation: bytes per launch at THIS run's launch count
                 "traffic": (traffic["hbm_bytes_per_launch"] * traffic["launches"] / (r["upd_launches"] / a.steps))

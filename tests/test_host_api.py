@@ -273,10 +273,14 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
         return hits[0]
 
     for t in ("d", "f"):
-        upd = find("k_trail_updateI%sLb1E" % t)
-        assert 2 * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
+        # fp64 ships the eight-wave update (two waves of a workgroup per SIMD), fp32 the four-wave one
+        upd, per_simd = (find("k_trail_update_w8IdLi3E"), 2) if t == "d" else (find("k_trail_updateIfLb1E"), 1)
+        assert 2 * per_simd * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
         for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE",
                       "k_solve_smallI%sE", "k_small_updateI%sE"):
             g = find(guest % t)
-            assert g["vgprs"] + upd["vgprs"] <= 512, (guest % t, g, upd)
+            assert g["vgprs"] + per_simd * upd["vgprs"] <= 512, (guest % t, g, upd)
             assert g["lds"] + upd["lds"] <= 160 * 1024, (guest % t, g, upd)
+    # the four-wave fp64 kernel stays selectable (CHOLMI_VARIANT=0): same budget
+    upd = find("k_trail_updateIdLb1E")
+    assert 2 * upd["vgprs"] <= 512 and find("k_potrf_diagIdE")["vgprs"] + upd["vgprs"] <= 512
