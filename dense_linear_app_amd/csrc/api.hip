@@ -1190,6 +1190,10 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "bench_update before chol_init");
   if (!d || !ms || d->p * d->q != 1 || !d->on_device || d->mt != d->nt || k < 0 || k + 1 >= d->nt || reps < 1)
     return fail(-1, "bench_update: arguments");
+#ifndef CHOLMI_DIAGNOSTICS
+  if (ablate != 0)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "bench_update: the ablation twin of the update is a diagnostic build (make DIAG=1)");
+#endif
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = ensure_events(2);
   if (rc) return rc;

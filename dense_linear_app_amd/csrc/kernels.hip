@@ -514,6 +514,7 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
   return true;
 }
 
+#ifdef CHOLMI_DIAGNOSTICS  // diagnostic twin of the update (register staging, ablation switches): make DIAG=1
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const int2 *__restrict__ list,
                                                          int na, int offb, int nb, int blocks_a, PanelRef pan,
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const 
   nt_kloop<T, false, false>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, 0, 0, ablate);
   nt_epilogue<T>(Cp, C.mb, acc, T(-1), (ablate & 4) ? T(0) : T(1), diag && mi == mj, 0, 0);
 }
+#endif
 
 // npan = 2: the updates by two consecutive panels in one pass, C(i,j) -= L(i,k-1) L(j,k-1)^T +
 // L(i,k) L(j,k)^T -- one K-loop of twice the length per C block (the walker defers the far columns'
@@ -1953,9 +1955,13 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   long blocks_b = ((tot_b + unit - 1) / unit + 7) / 8 * 8 * unit;
   if (na == 0 && nb == 1) blocks_a = 0, blocks_b = MTd;  // single diagonal tile: spread, no padding
   const dim3 grid((unsigned)(blocks_a + blocks_b)), blk(256);
-  if (g_ablate & 0x100)  // diagnostic build of the same update (register staging, ablation switches)
+#ifdef CHOLMI_DIAGNOSTICS
+  if (g_ablate & 0x100) {  // diagnostic build of the same update (register staging, ablation switches)
     k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, g_ablate & 255);
-  else if (g_variant >= 2 && sizeof(T) == 8) {
+    return;
+  }
+#endif
+  if (g_variant >= 2 && sizeof(T) == 8) {
     if constexpr (sizeof(T) == 8) {
 #define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
                                                      yield ? g_ytab : nullptr, p2, npan)

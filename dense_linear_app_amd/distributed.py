@@ -219,10 +219,10 @@ class TorchTransport:
     device=n: HBM of cuda:n -- the stream the library names is drained before a group moves, since
     gloo knows nothing of HIP streams.  One group = all isend / irecv posted, then all waited for."""
 
-    def __init__(self, dist, device: Optional[int] = None):
+    def __init__(self, dist, device: Optional[int] = None, group=None):
         import torch
 
-        self.dist, self.torch, self.device = dist, torch, device
+        self.dist, self.torch, self.device, self.group = dist, torch, device, group
         self.ops: List = []
         self.keep: List = []
         self.nbytes = 0
@@ -270,7 +270,16 @@ class TorchTransport:
         def f():
             if self.device is not None:
                 self.torch.cuda.synchronize(self.device)
-            reqs = [self.dist.isend(t, peer) if kind == "s" else self.dist.irecv(t, peer) for kind, t, peer in self.ops]
+            if not self.ops:
+                return
+            if self.dist.get_backend(self.group) == "nccl":
+                # RCCL through torch: the sends and receives of a group must progress together
+                ops = [self.dist.P2POp(self.dist.isend if kind == "s" else self.dist.irecv, t, peer, self.group)
+                       for kind, t, peer in self.ops]
+                reqs = self.dist.batch_isend_irecv(ops)
+            else:
+                reqs = [self.dist.isend(t, peer, group=self.group) if kind == "s" else
+                        self.dist.irecv(t, peer, group=self.group) for kind, t, peer in self.ops]
             for r in reqs:
                 r.wait()
             if self.device is not None:
@@ -281,9 +290,9 @@ class TorchTransport:
     def _allreduce_max(self, ctx, value):
         def f():
             t = self.torch.tensor([value[0]], dtype=self.torch.int64)
-            if self.dist.get_backend() == "nccl":
+            if self.dist.get_backend(self.group) == "nccl":
                 t = t.cuda()
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
             value[0] = int(t.item())
         return self._guard(f)
 
@@ -301,10 +310,13 @@ def install_rccl_transport(dist) -> None:
     L = lib()
     rank, world = dist.get_rank(), dist.get_world_size()
     buf = (C.c_char * 128)()
-    if rank == 0:
-        check("chol_transport_rccl_unique_id", L.chol_transport_rccl_unique_id(buf))
-    box = [bytes(buf)]
+    box = [None]
+    if rank == 0:  # a failure here must reach every rank, or they wait in the broadcast for ever
+        rc = L.chol_transport_rccl_unique_id(buf)
+        box = [bytes(buf) if rc == 0 else L.chol_last_error().decode(errors="replace")]
     dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], bytes):
+        raise RuntimeError(f"chol_transport_rccl_unique_id failed on rank 0: {box[0]}")
     ident = (C.c_char * 128).from_buffer_copy(box[0])
     check("chol_transport_rccl_init", L.chol_transport_rccl_init(ident, rank, world))
 

@@ -177,8 +177,9 @@ int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launc
 int chol_set_profiling(int on);
 
 /* Diagnostic: time the trailing-update launch of wave k alone (best of `reps`), on whatever
- * data the descriptor holds (the matrix is modified).  ablate: 0 = the production kernel; bit
- * 0 no global loads, 1 no LDS fragment reads, 2 no C read, 3 no barriers (timing only). */
+ * data the descriptor holds (the matrix is modified).  ablate: 0 = the production kernel; other values
+ * select the ablation twin (bit 0 no global loads, 1 no LDS fragment reads, 2 no C read, 3 no barriers;
+ * timing only), which exists in diagnostic builds only (make DIAG=1; CHOL_ERR_NOT_SUPPORTED otherwise). */
 int chol_bench_update(chol_desc_t *desc, int k, int ablate, int reps, double *ms, double *flops);
 
 /* Diagnostic: enable = 1 starts recording, per diagonal-block workgroup, 8 words of 100 MHz

@@ -15,6 +15,10 @@ for N, B in cfgs:
         variants += [(D | 32, "diag: cache-hot global loads"), (D | 4, "diag: no C read"), (D | 1, "diag: no global loads"), (D | 2, "diag: no LDS reads"),
                      (D | 8, "diag: no barrier"), (D | 3, "diag: no gl+lds"), (D | 15, "diag: mfma+store only")]
     for abl, name in variants:
-        ms, tf = ch.bench_update(d, 0, abl, 3)
+        try:
+            ms, tf = ch.bench_update(d, 0, abl, 3)
+        except ch.CholmiError as e:  # ablation twin: diagnostic build only (make -C dense_linear_app_amd/csrc DIAG=1)
+            print(f"N={N} B={B} ablate={abl:2d} {name:28s} skipped: {e.msg}", flush=True)
+            continue
         print(f"N={N} B={B} ablate={abl:2d} {name:28s} {ms:8.3f} ms  {tf:6.2f} TF/s", flush=True)
     ch.CHAMELEON_Desc_Destroy(d)
