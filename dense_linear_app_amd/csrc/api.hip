@@ -649,6 +649,8 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
   if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);
+  if (const char *e = getenv("CHOLMI_LATE_DMA")) cholmi::g_late_dma = atoi(e);
+  if (const char *e = getenv("CHOLMI_F32_W8")) cholmi::g_f32_w8 = atoi(e);
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));

@@ -59,6 +59,8 @@ extern int g_intile_small;
 extern int g_trsm_small_max;
 extern int g_min_units;
 extern int g_trsm_fused_min;
+extern int g_late_dma;
+extern int g_f32_w8;
 extern unsigned long long *g_dbg;
 extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;

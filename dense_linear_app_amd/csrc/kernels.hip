@@ -210,7 +210,7 @@ struct alignas(16) SmemP {
   T b[2][BK][MACRO];
 };
 
-template <typename T, bool DMA>
+template <typename T, bool DMA, bool LATE = false>
 __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda,
                                                 const T *__restrict__ B, int ldb, int K, Acc<T> &acc,
                                                 SmemP<T> &sm, const int *yslot = nullptr) {
@@ -245,22 +245,26 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
   // [BK][128] image; wave w moves pieces w, w+4, ...
   constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024;  // per operand per slice
   constexpr int EPP = 1024 / (int)sizeof(T);                  // elements per piece
+  auto dma_piece = [&](int buf, int k0, int q) {
+    const int piece = q * 4 + w;
+    const int e = piece * EPP + lane * EPV;  // element index inside the slice image
+    const int kk = e / MACRO, r = e % MACRO;
+    T *la = &sm.a[buf][0][0] + piece * EPP;
+    T *lb = &sm.b[buf][0][0] + piece * EPP;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
+        (__attribute__((address_space(3))) void *)la, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+        (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
+  };
   auto dma = [&](int buf, int k0) {
 #pragma unroll
-    for (int q = 0; q < PIECES / 4; ++q) {
-      const int piece = q * 4 + w;
-      const int e = piece * EPP + lane * EPV;  // element index inside the slice image
-      const int kk = e / MACRO, r = e % MACRO;
-      T *la = &sm.a[buf][0][0] + piece * EPP;
-      T *lb = &sm.b[buf][0][0] + piece * EPP;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
-          (__attribute__((address_space(3))) void *)la, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
-          (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
-    }
+    for (int q = 0; q < PIECES / 4; ++q) dma_piece(buf, k0, q);
   };
+  // LATE: the next slice's DMA goes out behind the first MFMA of k-groups 0 and 1 instead of in one
+  // burst between the barrier and the slice's first MFMA (kernels.hip: nt_kloop_w8, MODE bit 0)
+  constexpr int PPG = PIECES / 4 / 2;  // pieces per operand, wave and early k-group
   vec_t fa[2][NG], fb[2][NG];
   const int arow = wr * 64 + EPV * (lane & 15), brow = wc * 64 + EPV * (lane & 15), kq = lane >> 4;
   auto fread = [&](int set, int cur, int ks) {
@@ -285,10 +289,11 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
     if (yslot) guest = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fread(0, cur, 0);
     if (kt + 1 < nk) {
-      if (DMA)
-        dma(cur ^ 1, (kt + 1) * BK);
-      else
+      if (DMA) {
+        if (!LATE) dma(cur ^ 1, (kt + 1) * BK);
+      } else {
         gload((kt + 1) * BK);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -299,6 +304,10 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = Tr<T>::mfma(fb[ks & 1][0][0], fa[ks & 1][0][0], acc[0][0]);
       __builtin_amdgcn_sched_barrier(0);
+      if (DMA && LATE && ks < 2 && kt + 1 < nk) {
+#pragma unroll
+        for (int q = 0; q < PPG; ++q) dma_piece(cur ^ 1, (kt + 1) * BK, ks * PPG + q);
+      }
       if (ks + 1 < BK / 4)
         fread((ks + 1) & 1, cur, ks + 1);
       else if (!DMA && kt + 1 < nk)
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const 
 // npan = 2: the updates by two consecutive panels in one pass, C(i,j) -= L(i,k-1) L(j,k-1)^T +
 // L(i,k) L(j,k)^T -- one K-loop of twice the length per C block (the walker defers the far columns'
 // update by the even panel of a pair): half the C traffic, prologues and epilogues per flop.
-template <typename T, bool DMA>
+template <typename T, bool DMA, bool LATE = false>
 __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
                                                            int na, int offb, int nb, int blocks_a, PanelRef pan,
                                                            int nbm, int unit, const int *ytab, PanelRef pan2,
@@ -557,9 +566,9 @@ __global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 
   Acc<T> acc;
   acc_zero<T>(acc);
   const int *yslot = ytab ? ytab + cu_slot() : nullptr;
-  nt_kloop_paired<T, DMA>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, yslot);
+  nt_kloop_paired<T, DMA, LATE>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, yslot);
   if (npan > 1)
-    nt_kloop_paired<T, DMA>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
+    nt_kloop_paired<T, DMA, LATE>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
                             panel_tile<T>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
   if (diag && mi == mj)
     nt_epilogue_paired_impl<T, true>(Cp, C.mb, acc, T(-1), T(1));
@@ -695,6 +704,127 @@ __global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const in
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// ------------------------------------------------------------------------------
+// fp32 trailing update on eight waves with K-slices of 32.  The fp32 16x16x4 MFMA issues every 32
+// cycles (twice the fp64 rate), so with 16-deep slices a wave meets a barrier after 2048 cycles of
+// matrix work and the per-slice stalls weigh twice as much as in fp64 (81 % of peak against 86 %).
+// Slices of 32 (2 x 32 KiB LDS buffers, two workgroups per CU) restore the fp64 kernel's 4096 matrix
+// cycles per wave and barrier at the same four waves per SIMD.  Wave tile 64 rows x 32 columns: the A
+// fragment is one 16-byte read (rows 4i..4i+3 of the 64-row group), the B fragment one 8-byte read
+// (columns 2i, 2i+1); accumulator register r of tile (a, b) in lane (i, q) is element
+// (row 64 wr + 4i + a, column 32 wc + 2 (4q + r) + b).
+// ------------------------------------------------------------------------------
+constexpr int BKF = 32;
+struct alignas(16) SmemF {
+  float a[2][BKF][MACRO];
+  float b[2][BKF][MACRO];
+};
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void nt_kloop_w8f(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                             int ldb, int K, f4_t (&acc)[4][2], SmemF &sm, const int *yslot) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  constexpr int PIECES = BKF * MACRO * 4 / 1024, EPP = 256;  // 16 one-KiB pieces per operand and slice
+  auto dma = [&](int buf, int k0) {
+#pragma unroll
+    for (int p = 0; p < PIECES / 8; ++p) {
+      const int piece = p * 8 + w;
+      const int e = piece * EPP + lane * 4;
+      const int kk = e / MACRO, r = e % MACRO;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
+          (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
+    }
+  };
+  f4_t fa[2];
+  f2_t fb[2];
+  const int arow = wr * 64 + 4 * i, brow = wc * 32 + 2 * i;
+  auto fread = [&](int set, int cur, int ks) {
+    fa[set] = *reinterpret_cast<const f4_t *>(&sm.a[cur][ks * 4 + q][arow]);
+    fb[set] = *reinterpret_cast<const f2_t *>(&sm.b[cur][ks * 4 + q][brow]);
+  };
+  dma(0, 0);
+  __syncthreads();
+  const int nk = K / BKF;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    int guest = 0;
+    if (yslot) guest = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fread(0, cur, 0);
+    if (kt + 1 < nk) dma(cur ^ 1, (kt + 1) * BKF);
+#pragma unroll
+    for (int ks = 0; ks < BKF / 4; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = Tr<float>::mfma(fb[ks & 1][0], fa[ks & 1][0], acc[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < BKF / 4) fread((ks + 1) & 1, cur, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (a + b > 0) acc[a][b] = Tr<float>::mfma(fb[ks & 1][b], fa[ks & 1][a], acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (yslot && __builtin_amdgcn_readfirstlane(guest) != 0) yield_to_guest(yslot);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void k_trail_update_w8f(LocalMat C, const int2 *__restrict__ list, int na,
+                                                              int offb, int nb, int blocks_a, PanelRef pan, int nbm,
+                                                              int unit, const int *ytab, PanelRef pan2, int npan) {
+  __shared__ SmemF sm;
+  BlockMap bm;
+  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
+  const int2 ij = bm.ij;
+  const int mi = bm.mi, mj = bm.mj;
+  const bool lower = (ij.x == ij.y) && mi == mj;
+  float *Cp = reinterpret_cast<float *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
+              mi * MACRO + (long)mj * MACRO * C.mb;
+  f4_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
+  nt_kloop_w8f(panel_tile<float>(pan, ij.x, C.bsiz) + mi * MACRO, C.mb,
+               panel_tile<float>(pan, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
+  if (npan > 1)
+    nt_kloop_w8f(panel_tile<float>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
+                 panel_tile<float>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  const int m0 = wr * 64 + 4 * i;
+  f4_t cv[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      cv[b][r] = *reinterpret_cast<const f4_t *>(Cp + (long)(wc * 32 + 2 * (4 * q + r) + b) * C.mb + m0);
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 32 + 2 * (4 * q + r) + b;
+      float *col = Cp + (long)n * C.mb;
+      f4_t v = cv[b][r];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) v[a] -= acc[a][b][r];
+      if (!lower || m0 >= n) {
+        *reinterpret_cast<f4_t *>(col + m0) = v;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          if (m0 + a >= n) col[m0 + a] = v[a];
+      }
+    }
 }
 
 // X[:, s] := alpha * A[:, s] * Winv_s^T, in place, for row blocks r >= r0 of `ntiles`
@@ -1938,6 +2068,8 @@ int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTI
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
+int g_late_dma = 0;  // four-wave update (fp32; fp64 with CHOLMI_VARIANT=0): DMA behind the first MFMAs -- fp64 +0.9 %, fp32 -6.6 % (twice the MFMA rate: the burst is better out of the way early); CHOLMI_LATE_DMA
+int g_f32_w8 = 1;  // fp32 trailing update on eight waves with K-slices of 32 (CHOLMI_F32_W8=0: the four-wave kernel)
 int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
 
 template <typename T>
@@ -1961,6 +2093,12 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
     return;
   }
 #endif
+  if (g_variant >= 2 && sizeof(T) == 4 && g_f32_w8) {
+    if constexpr (sizeof(T) == 4)
+      k_trail_update_w8f<<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
+                                                   yield ? g_ytab : nullptr, p2, npan);
+    return;
+  }
   if (g_variant >= 2 && sizeof(T) == 8) {
     if constexpr (sizeof(T) == 8) {
 #define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
@@ -1976,6 +2114,9 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   } else if (g_variant == 1)
     k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                   yield ? g_ytab : nullptr, p2, npan);
+  else if (g_late_dma)
+    k_trail_update<T, true, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
+                                                       yield ? g_ytab : nullptr, p2, npan);
   else
     k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                  yield ? g_ytab : nullptr, p2, npan);
