@@ -199,7 +199,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   const int nbm = mb / MACRO;
   enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_PER_WAVE };
   enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
-  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm);
+  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm + 1);
   if (rc) return rc;
   auto ev = [&](int k, int which) { return g.events[(size_t)E_PER_WAVE * k + which]; };
   hipEvent_t *fixed = &g.events[(size_t)E_PER_WAVE * nt];
@@ -212,6 +212,12 @@ int potrf_full_device(chol_desc *d, void *base) {
   // leaves the chip short of work once the panel chain is what a wave waits for
   static const double pair_fac = getenv("CHOLMI_PAIR_FACTOR") ? atof(getenv("CHOLMI_PAIR_FACTOR")) : 2.0;
   bool paired = false, cols_pending = false;  // paired: this wave belongs to a pair (decided at its even wave)
+  bool had_pairs = false;
+  // experiment, off: keep the chain-critical launches of a chain-bound wave (the head tile's last TRSM step, the
+  // SYRK on the next diagonal tile) on s_panel instead of crossing streams.  Measured -1 ... -2 % at N <= 16384
+  // (the hops it removes were overlapped work, not latency); CHOLMI_CHAIN_INSTREAM=1 enables it.
+  static const bool chain_enabled = getenv("CHOLMI_CHAIN_INSTREAM") && atoi(getenv("CHOLMI_CHAIN_INSTREAM")) != 0;
+  static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
   int open_bracket = -1;                      // odd wave whose profiling bracket is still open
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
@@ -229,11 +235,22 @@ int potrf_full_device(chol_desc *d, void *base) {
     T *lkk = M + ((long)k + (long)k * nt) * bsiz;
     HIPCHECK(hipStreamWaitEvent(g.s_trsm, fixed[F_WAVE], 0));
     if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev(k - 1, E_U1R), 0));
-    launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv, g.d_info, k * mb, lkk + bsiz, bsiz,
-                              nt - 1 - k, fixed[F_HEAD]);
-    HIPCHECK(hipEventRecord(fixed[F_TRSM], g.s_trsm));
-    HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_TRSM], 0));
-    HIPCHECK(hipEventRecord(ev(k, E_PANEL), g.s_panel));
+    // chain: this wave is about as long as its panel chain -- keep the chain's own launches on s_panel
+    const double mrem = nt - 1 - k;
+    const bool chain = chain_enabled && cholmi::g_intile_small && k + 1 < nt &&
+                       mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < yfac * (nbm * 130e-6 * 1.5);
+    // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite
+    // its set while TRSM(k) still reads the other
+    T *winv_k = winv + (size_t)(k & 1) * (g.winv_bytes / sizeof(T));
+    launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv_k, g.d_info, k * mb, lkk + bsiz, bsiz,
+                              nt - 1 - k, fixed[F_HEAD], chain, k > 0 ? ev(k - 1, E_U1R) : nullptr);
+    // TRSM(k) complete = panel k ready (s_trsm has waited for every POTRF step, and for the head tile's
+    // in-stream step in chain mode).
+    HIPCHECK(hipEventRecord(ev(k, E_PANEL), g.s_trsm));
+    // In chain mode s_panel does not wait for it: POTRF(k+1) needs the SYRK only, and TRSM(k) is over
+    // before POTRF(k+2) reuses its workspace (the head tile's last step of TRSM(k+1) waits for the
+    // earlier ones, which follow TRSM(k) in stream order -- with more than one step per tile).
+    if (!chain || nbm == 1) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_PANEL), 0));
     if (k + 1 >= nt) break;
     // trailing update (C2:540-560)
     auto panel_ref = [&](int kk) {
@@ -266,7 +283,6 @@ int potrf_full_device(chol_desc *d, void *base) {
       const ColRange c1 = rng(k + 1, k + 2), ca = rng(k + 2, k + 3), cb = rng(k + 3, k + 4), big = rng(k + 4, nt);
       const int wave_tiles = c1.na + c1.nb + (odd ? ca.na + ca.nb + cb.na + cb.nb + big.na + big.nb : 0);
       const double t_tile = 2.0 * b3 / 65e12 * (odd ? 2 : 1), t_panel = nbm * 130e-6 * 1.5;
-      static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
       const bool yield = (double)wave_tiles * t_tile < yfac * t_panel * (odd ? 2 : 1);
       hipStream_t su = concurrent ? g.s_u1 : g.s_main;
       T *ckk = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
@@ -295,6 +311,7 @@ int potrf_full_device(chol_desc *d, void *base) {
         if (cb.na + cb.nb > 0) ++timed, fl += 2.0 * cb.na + cb.nb;
         HIPCHECK(hipEventRecord(fixed[F_COLS], su));
         cols_pending = true;
+        had_pairs = true;
         HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
         if (g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
         launch_trail_update<T>(g.s_main, C, d->d_list, big.off, big.na, big.offb, big.nb, p1, yield, p2);
@@ -340,13 +357,25 @@ int potrf_full_device(chol_desc *d, void *base) {
     // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
     const double t_tile = 2.0 * b3 / 65e12;
     const double t_panel = nbm * 130e-6 * 1.5;
-    static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
     const bool yield = (double)(r1.na + r1.nb + r2.na + r2.nb) * t_tile < yfac * t_panel;
     static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
     const bool split = yield || split_always;
     hipStream_t su = concurrent ? g.s_u1 : g.s_main;
+    const bool syrk_instream = chain && split && concurrent && !paired;
+    if (syrk_instream) {
+      // the SYRK that releases POTRF(k+1) directly behind the head tile's TRSM on s_panel; the earlier
+      // writers of tile (k+1,k+1) -- the previous waves' updates -- finished long ago in this regime
+      if (k > 0) {
+        HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k - 1, E_U2), 0));
+        HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k - 1, E_U1R), 0));
+      }
+      if (had_pairs) HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_COLS], 0));
+      launch_diag_syrk<T>(g.s_panel, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
+                          M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
+      HIPCHECK(hipEventRecord(ev(k, E_U1D), g.s_panel));
+    }
     // the SYRK on (k+1,k+1) needs the head tile L(k+1,k) only; everything else the whole panel
-    HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
+    HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small && !syrk_instream) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
     if (cols_pending) {  // first plain wave after the paired phase: Cb of the last pair wrote column k+2
       HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
       cols_pending = false;
@@ -361,14 +390,17 @@ int potrf_full_device(chol_desc *d, void *base) {
     if (split) {
       // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
       // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
-      if (cholmi::g_intile_small) {
+      if (syrk_instream) {
+        // (done above, on s_panel)
+      } else if (cholmi::g_intile_small) {
         launch_diag_syrk<T>(su, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
                             M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
+        HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       } else {
         launch_trail_update<T>(su, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
         ++timed;
+        HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       }
-      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
       launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
       if (r1.na > 0) ++timed;
@@ -380,7 +412,7 @@ int potrf_full_device(chol_desc *d, void *base) {
       HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
     }
-    HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
+    if (!syrk_instream) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
     if (concurrent && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
     if (r2.na + r2.nb > 0) {
       launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
@@ -405,6 +437,8 @@ int potrf_full_device(chol_desc *d, void *base) {
   }
   HIPCHECK(hipEventRecord(fixed[F_JOIN], g.s_panel));
   HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_JOIN], 0));
+  HIPCHECK(hipEventRecord(fixed[F_TRSM], g.s_trsm));
+  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_TRSM], 0));
   HIPCHECK(hipEventRecord(fixed[F_U1END], g.s_u1));
   HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_U1END], 0));
   HIPCHECK(hipEventRecord(fixed[F_STOP], g.s_main));
@@ -652,7 +686,7 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_LATE_DMA")) cholmi::g_late_dma = atoi(e);
   if (const char *e = getenv("CHOLMI_F32_W8")) cholmi::g_f32_w8 = atoi(e);
   g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
-  HIPCHECK(hipMalloc(&g.winv, g.winv_bytes));
+  HIPCHECK(hipMalloc(&g.winv, 2 * g.winv_bytes));  // two sets: the walker alternates them by wave parity
   HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
   HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
   HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));

@@ -2198,42 +2198,59 @@ void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
 // ev: nbm events.  Both streams must be joined by the caller.
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
-                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head) {
+                            int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
+                            bool chain, hipEvent_t ev_col) {
   const int nbm = mb / MACRO;
   const bool fused = trsm_fused_applies<T>(ntiles - 1, mb);
   const int nstep = fused ? 1 : ntiles;  // tiles that follow the POTRF step by step
+  // chain: the wave is as long as its panel chain (late waves, small matrices).  A dependency that
+  // crosses streams costs 14-19 us of wake-up latency where one inside a stream costs ~1 us, so the
+  // chain's own work -- the head tile's last TRSM step (the earlier ones ran beside the POTRF) -- stays
+  // on sp; the caller does the same with the SYRK on the next diagonal tile.
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
     k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
                                        d_info, info_base + s * MACRO, 1, g_dbg, g_ytab);
     if (nr > 0) {
-      if (g_intile_small)
-        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab);
-      else
-        k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
-    }
-    if (ntiles > 0) {
-      (void)hipEventRecord(ev[s], sp);
-      (void)hipStreamWaitEvent(st, ev[s], 0);
-      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
-    }
-    if (nr > 0) {
       if (g_intile_small) {
+        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab);
         T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
         const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
         k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
       } else {
+        k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
         k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
       }
     }
+    if (ntiles <= 0) continue;
+    // (recorded behind the in-tile update, not between the solve and the update: an event record
+    // between two dependent launches of the chain costs it ~7 us, the TRSM step loses nothing)
+    (void)hipEventRecord(ev[s], sp);
+    if (chain && s == nbm - 1) {
+      // the head tile's earlier steps (on st, which waited for the panel's column to be up to date);
+      // with one step per tile sp itself must wait for that column: ev_col
+      if (nbm > 1)
+        (void)hipStreamWaitEvent(sp, ev[nbm], 0);
+      else if (ev_col)
+        (void)hipStreamWaitEvent(sp, ev_col, 0);
+      trsm_step<T>(sp, tiles, bsiz, 1, lkk, winv, mb, s, T(1));
+      if (ev_head) (void)hipEventRecord(ev_head, sp);
+      (void)hipStreamWaitEvent(st, ev[s], 0);
+      if (nstep > 1) trsm_step<T>(st, tiles + bsiz, bsiz, nstep - 1, lkk, winv, mb, s, T(1));
+      if (ev_head) (void)hipStreamWaitEvent(st, ev_head, 0);  // what the caller records on st next covers the head tile
+    } else {
+      (void)hipStreamWaitEvent(st, ev[s], 0);
+      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
+      if (chain && s == nbm - 2) (void)hipEventRecord(ev[nbm], st);
+    }
   }
-  if (ev_head) (void)hipEventRecord(ev_head, st);
+  if (ev_head && !(chain && ntiles > 0)) (void)hipEventRecord(ev_head, st);
   if (fused) launch_trsm_fused<T>(st, tiles + bsiz, bsiz, ntiles - 1, lkk, winv, mb);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
-                                             int *, int, double *, long, int, hipEvent_t);
+                                             int *, int, double *, long, int, hipEvent_t, bool, hipEvent_t);
 template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
-                                            int, float *, long, int, hipEvent_t);
+                                            int, float *, long, int, hipEvent_t, bool, hipEvent_t);
 
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
