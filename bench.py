@@ -251,6 +251,11 @@ def main() -> int:
                 if traffic and traffic.get("N") == a.N and traffic.get("tile") == a.tile else None,
                 "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
                 "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
+                # the launches of a wave run side by side: the HIP-event brackets
+                # measure the wall time in which they run (the UNION of their intervals), so
+                # avg_launch_ms = union / launches; rocprof's per-kernel sum of durations counts the
+                # overlap twice (profiles/r02_bench_union_busy.txt: sum / union = 1.24, union = brackets)
+                "time_base": "union of concurrent launches",
             }
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
