@@ -61,7 +61,7 @@ for k, w0 in enumerate(waves):
     nu = sum(1 for s, e, n in rows if upd(n) and w0 <= s < w1)
     np_ = sum(1 for s, e, n in rows if pan(n) and w0 <= s < w1)
     tot_gap += (w1 - w0) - ubk
-    if k < 8 or k % 8 == 0 or k + 4 > len(waves):
+    if True:
         print(f"{k:4d} {(w1 - w0) / 1e3:9.1f} {ubk / 1e3:9.1f} {(w1 - w0 - ubk) / 1e3:9.1f} {pbk / 1e3:9.1f} {nu:4d} {np_:4d}")
 print(f"# sum over waves of time without an update kernel running: {tot_gap / 1e6:.3f} ms of {(tend - t0) / 1e6:.3f} ms")
 # launch-level: duration of every update launch vs its share of flops is not in the trace; report the
