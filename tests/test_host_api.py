@@ -274,13 +274,49 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
 
     for t in ("d", "f"):
         # fp64 ships the eight-wave update (two waves of a workgroup per SIMD), fp32 the four-wave one
-        upd, per_simd = (find("k_trail_update_w8IdLi3E"), 2) if t == "d" else (find("k_trail_updateIfLb1E"), 1)
+        # both ship the eight-wave update (two waves of a workgroup per SIMD)
+        upd, per_simd = (find("k_trail_update_w8IdLi3E"), 2) if t == "d" else (find("k_trail_update_w8f"), 2)
         assert 2 * per_simd * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
         for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE",
                       "k_solve_smallI%sE", "k_small_updateI%sE"):
             g = find(guest % t)
             assert g["vgprs"] + per_simd * upd["vgprs"] <= 512, (guest % t, g, upd)
             assert g["lds"] + upd["lds"] <= 160 * 1024, (guest % t, g, upd)
-    # the four-wave fp64 kernel stays selectable (CHOLMI_VARIANT=0): same budget
-    upd = find("k_trail_updateIdLb1E")
-    assert 2 * upd["vgprs"] <= 512 and find("k_potrf_diagIdE")["vgprs"] + upd["vgprs"] <= 512
+    # the four-wave kernels stay selectable (CHOLMI_VARIANT=0, CHOLMI_F32_W8=0): same budget
+    for name, diag in (("k_trail_updateIdLb1ELb0E", "k_potrf_diagIdE"), ("k_trail_updateIfLb1ELb0E", "k_potrf_diagIfE")):
+        upd = find(name)
+        assert 2 * upd["vgprs"] <= 512 and find(diag)["vgprs"] + upd["vgprs"] <= 512
+
+
+def test_v3_long_option_front_end_argument_checks():
+    """The reference's v3 driver validates before it touches Chameleon (v3:122-195): the same
+    checks run here without a GPU (every path below returns before CHAMELEON_Init)."""
+    import io
+
+    from dense_linear_app_amd import driver
+
+    base = {"N": 2048, "NB": 256, "ncpu": 1, "ngpu": 1, "mat": "none", "dtyp": "d", "mb": 256, "nb": 256,
+            "bsiz": 65536, "lm": 2048, "ln": 2048, "i": 0, "j": 0, "m": 2048, "n": 2048, "p": 1, "q": 1,
+            "bump": 2048, "uplo": "L", "seed": 51}
+
+    def run(**kw):
+        d = dict(base, **kw)
+        argv = []
+        for k, v in d.items():
+            if v is not None:
+                argv += [f"--{k}", str(v)]
+        err = io.StringIO()
+        return driver.v3_test(argv, out=io.StringIO(), err=err), err.getvalue()
+
+    rc, err = run(seed=None)
+    assert rc == 1 and "all options are required" in err
+    assert run(uplo="X") == (1, "Error: invalid --uplo X\n")
+    assert run(dtyp="q") == (1, "Error: invalid --dtyp q\n")
+    rc, err = run(dtyp="z")
+    assert rc == 1 and "complex" in err
+    assert run(mb=0)[1] == "Error: dimension arguments must be >0.\n"
+    assert run(bsiz=100)[1] == "Error: --bsiz < mb*nb (bsiz=100 mb=256 nb=256).\n"
+    assert run(i=4096)[1] == "Error: invalid offsets i=4096 j=0 (lm=2048 ln=2048).\n"
+    assert "outside lm=2048" in run(i=512)[1]
+    assert driver.v3_test(["--help"], out=io.StringIO(), err=io.StringIO()) == 0
+    assert driver.v3_test(["--bogus", "1"], out=io.StringIO(), err=io.StringIO()) == 1
