@@ -736,14 +736,16 @@ __device__ __forceinline__ void nt_kloop_w8f(const float *__restrict__ A, int ld
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
           (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
+      // B image: odd k-rows rotated by 32 columns (on the SOURCE address -- the DMA writes LDS linearly):
+      // the 8-byte fragment reads of the two k-rows of a 32-lane group then fall on opposite bank halves
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+          (const __attribute__((address_space(1))) void *)(B + ((r + 32 * (kk & 1)) & (MACRO - 1)) + (size_t)(k0 + kk) * ldb),
           (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
     }
   };
   f4_t fa[2];
   f2_t fb[2];
-  const int arow = wr * 64 + 4 * i, brow = wc * 32 + 2 * i;
+  const int arow = wr * 64 + 4 * i, brow = (wc * 32 + 2 * i - 32 * (q & 1)) & (MACRO - 1);  // (4 ks + q) & 1 == q & 1
   auto fread = [&](int set, int cur, int ks) {
     fa[set] = *reinterpret_cast<const f4_t *>(&sm.a[cur][ks * 4 + q][arow]);
     fb[set] = *reinterpret_cast<const f2_t *>(&sm.b[cur][ks * 4 + q][brow]);
