@@ -302,3 +302,39 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
     assert np.array_equal(dB.to_lapack(), Bm.astype(npdt))
     with pytest.raises(ch.CholmiError):
         ch.CHAMELEON_dpotrs_Tile(ch.ChamUpper, dA, dB)
+
+
+@pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_U1_CONCURRENT": "0"},
+                                 {"CHOLMI_PAIR_MAX_MB": "0", "CHOLMI_VARIANT": "0"}, {"CHOLMI_TRSM_FUSED_MIN": "1"},
+                                 {"CHOLMI_CHAIN_INSTREAM": "1", "CHOLMI_PAIR_FACTOR": "0"}])
+def test_walker_schedule_variants_match_the_oracle(env, orc):
+    """The walker picks its schedule by size (two panels per pass only while a wave's update is long, and so
+    on), so at oracle-sized problems the default run never enters some of them.  Each variant forced through
+    its environment switch in a fresh process (the switches are read once): factor vs the oracle's, element
+    by element, fp64 and fp32."""
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    N, B = 3072, 256  # 12 tiles per side
+    with tempfile.TemporaryDirectory() as tmp:
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from dense_linear_app_amd import chameleon as ch\n"
+            "ch.CHAMELEON_Init(1, 1)\n"
+            "for name, dt in (('d', ch.ChamRealDouble), ('s', ch.ChamRealFloat)):\n"
+            "    d = ch.CHAMELEON_Desc_Create(None, dt, %d, %d, %d, %d, %d, 0, 0, %d, %d, 1, 1)\n"
+            "    ch.CHAMELEON_dplgsy_Tile(float(%d), ch.ChamLower, d, 42)\n"
+            "    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)\n"
+            "    np.save(%r + '/L' + name + '.npy', d.to_lapack()); print(name, info)\n"
+        ) % (root, B, B, B * B, N, N, N, N, N, tmp)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "d 0" in r.stdout and "s 0" in r.stdout, (r.stdout, r.stderr[-2000:])
+        Ld, Ls = np.load(tmp + "/Ld.npy"), np.load(tmp + "/Ls.npy")
+    T = orc.plgsy_tiles(N // B, B, float(N), 42)
+    assert orc.tiled_potrf(T, N // B, B) == 0
+    Lref = np.tril(orc.tile_to_lapack(T, N, B))
+    assert np.abs(np.tril(Ld) - Lref).max() / np.abs(Lref).max() <= 1e-12
+    assert np.abs(np.tril(Ls).astype(np.float64) - Lref).max() / np.abs(Lref).max() <= 1e-4
