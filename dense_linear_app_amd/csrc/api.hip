@@ -587,11 +587,11 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
   const size_t tb = (size_t)bs * sizeof(T);
   T *La = reinterpret_cast<T *>(A->mat), *Bm = reinterpret_cast<T *>(B->mat);
   T *scr = nullptr;
-  if (hipMalloc(&scr, ((size_t)nr * nt + 3) * tb) != hipSuccess) {
+  if (hipMalloc(&scr, ((size_t)nr * nt + 2 + (size_t)nr + (size_t)nt) * tb) != hipSuccess) {
     (void)hipGetLastError();
     return fail(CHOL_ERR_OUT_OF_MEMORY, "potrs_tile: scratch allocation failed");
   }
-  T *Z = scr, *Wt = scr + (size_t)nr * nt * bs, *Tt = Wt + bs, *tmp = Tt + bs;
+  T *Z = scr, *Wt = scr + (size_t)nr * nt * bs, *Tt = Wt + bs, *tmp = Tt + (size_t)nt * bs;  // Tt: nt tiles, tmp: nr tiles
   hipStream_t s = g.s_main;
   T *winv = reinterpret_cast<T *>(g.winv);
   auto Ltile = [&](int i, int j) { return La + ((long)i + (long)j * A->lmt) * bs; };
@@ -602,23 +602,22 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
   for (int k = 0; k < nt; ++k) {  // forward
     launch_invert_diag<T>(s, Ltile(k, k), mb, winv);
     launch_trsm_panel<T>(s, Ztile(0, k), bs, nr, Ltile(k, k), winv, mb, T(1));
-    for (int i = k + 1; i < nt; ++i)
-      for (int r = 0; r < nr; ++r)
-        launch_gemm_nt_tile<T>(s, Ztile(r, k), Ltile(i, k), Ztile(r, i), mb, T(-1), T(1), false);
+    // Z(r,i) -= Z(r,k) L(i,k)^T for every r and i > k: one launch
+    launch_gemm_nt_batch<T>(s, Ztile(0, k), bs, nr, Ltile(k + 1, k), bs, nt - 1 - k, Ztile(0, k + 1), bs, (long)nr * bs, mb,
+                            T(-1), T(1));
   }
   for (int k = nt - 1; k >= 0; --k) {  // backward
     HIPCHECK(hipMemsetAsync(Wt, 0, tb, s));
     launch_pad_identity<T>(s, Wt, 0, mb);
     launch_invert_diag<T>(s, Ltile(k, k), mb, winv);
     launch_trsm_panel<T>(s, Wt, bs, 1, Ltile(k, k), winv, mb, T(1));  // Wt = L(k,k)^{-T}
-    for (int r = 0; r < nr; ++r) {
-      launch_gemm_nt_tile<T>(s, Ztile(r, k), Wt, tmp, mb, T(1), T(0), false);  // Z(r,k) L(k,k)^{-1}
-      HIPCHECK(hipMemcpyAsync(Ztile(r, k), tmp, tb, hipMemcpyDeviceToDevice, s));
-    }
-    for (int i = 0; i < k; ++i) {
-      launch_tiles_transpose<T>(s, Ltile(k, i), bs, Tt, bs, mb, 1);  // Tt = L(k,i)^T
-      for (int r = 0; r < nr; ++r)
-        launch_gemm_nt_tile<T>(s, Ztile(r, k), Tt, Ztile(r, i), mb, T(-1), T(1), false);
+    // Z(r,k) <- Z(r,k) L(k,k)^{-1} for every r (out of place, then back: the tiles of a column are contiguous)
+    launch_gemm_nt_batch<T>(s, Ztile(0, k), bs, nr, Wt, 0, 1, tmp, bs, 0, mb, T(1), T(0));
+    HIPCHECK(hipMemcpyAsync(Ztile(0, k), tmp, (size_t)nr * tb, hipMemcpyDeviceToDevice, s));
+    // Z(r,i) -= Z(r,k) L(k,i) for every r and i < k: the k tiles L(k,i)^T in one transpose launch, one product launch
+    if (k > 0) {
+      launch_tiles_transpose<T>(s, Ltile(k, 0), (long)A->lmt * bs, Tt, bs, mb, k);
+      launch_gemm_nt_batch<T>(s, Ztile(0, k), bs, nr, Tt, bs, k, Ztile(0, 0), bs, (long)nr * bs, mb, T(-1), T(1));
     }
   }
   for (int r = 0; r < nr; ++r)  // B(i,r) = Z(r,i)^T

@@ -111,6 +111,11 @@ template <typename T>
 void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T alpha, T beta,
                          bool lower_only);
 
+// the same product for nz1 x nz2 tiles in one launch: A + z1 sA, B + z2 sB, C + z1 sC1 + z2 sC2
+template <typename T>
+void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *B, long sB, int nz2, T *C, long sC1,
+                          long sC2, int mb, T alpha, T beta);
+
 template <typename T>
 void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,
                   unsigned long long seed, int mbu, long nglob, int side);

@@ -1230,13 +1230,22 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
 }
 
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
+// blockIdx.z = z1 + nz1 * z2 selects the tiles of a batch: A + z1 sA, B + z2 sB, C + z1 sC1 + z2 sC2
+// (potrs: Z(r,i) -= Z(r,k) L(i,k)^T for all right-hand-side tile rows r and tile columns i in one launch)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A,
                                                          const T *__restrict__ B, T *C, int mb,
-                                                         int nbm, T alpha, T beta, int lower) {
+                                                         int nbm, T alpha, T beta, int lower, int nz1, long sA,
+                                                         long sB, long sC1, long sC2) {
   __shared__ SmemP<T> sm;
   const int mi = blockIdx.x, mj = blockIdx.y;
   if (lower && mi < mj) return;
+  {
+    const int z1 = blockIdx.z % nz1, z2 = blockIdx.z / nz1;
+    A += z1 * sA;
+    B += z2 * sB;
+    C += z1 * sC1 + z2 * sC2;
+  }
   Acc<T> acc;
   acc_zero<T>(acc);
   nt_kloop_paired<T, true>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
@@ -2280,7 +2289,15 @@ template <typename T>
 void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T alpha, T beta,
                          bool lower_only) {
   const int nbm = mb / MACRO;
-  k_gemm_nt_tile<T><<<dim3(nbm, nbm), 256, 0, s>>>(A, B, C, mb, nbm, alpha, beta, lower_only ? 1 : 0);
+  k_gemm_nt_tile<T><<<dim3(nbm, nbm), 256, 0, s>>>(A, B, C, mb, nbm, alpha, beta, lower_only ? 1 : 0, 1, 0, 0, 0, 0);
+}
+
+template <typename T>
+void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *B, long sB, int nz2, T *C, long sC1,
+                          long sC2, int mb, T alpha, T beta) {
+  const int nbm = mb / MACRO;
+  if (nz1 > 0 && nz2 > 0)
+    k_gemm_nt_tile<T><<<dim3(nbm, nbm, nz1 * nz2), 256, 0, s>>>(A, B, C, mb, nbm, alpha, beta, 0, nz1, sA, sB, sC1, sC2);
 }
 
 template <typename T>
@@ -2346,6 +2363,8 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
   template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
   template void launch_gemm_nt_tile<T>(hipStream_t, const T *, const T *, T *, int, T, T, bool);    \
+  template void launch_gemm_nt_batch<T>(hipStream_t, const T *, long, int, const T *, long, int, T *, long, long, \
+                                        int, T, T);                                                 \
   template void launch_plgsy<T>(hipStream_t, const LocalMat &, int, int, int, double,               \
                                 unsigned long long, int, long, int);                                \
   template void launch_residual<T>(hipStream_t, const T *, int, int, double, unsigned long long,    \
