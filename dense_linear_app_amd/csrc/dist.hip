@@ -612,6 +612,10 @@ int chol_internal_dist_potrf(chol_desc *d, int rank) {
   long long info = 0;
   static const bool lookahead = !(getenv("CHOLMI_DIST_LOOKAHEAD") && atoi(getenv("CHOLMI_DIST_LOOKAHEAD")) == 0);
   if (!rc) rc = dist.factorize(lookahead, &info);
+  if (rc) {  // leave nothing half-open behind a failure: close the transport group, drain the streams
+    (void)dist.end();
+    (void)eng.sync();
+  }
   g_pool.release_all();
   g_last_issue_us_per_wave = dist.issue_us / (eng.nt > 0 ? eng.nt : 1);
   g_last_sends = dist.nsend, g_last_recvs = dist.nrecv, g_last_bytes = dist.bytes_sent;
@@ -683,6 +687,7 @@ int chol_dist_factorize_with(const chol_test_engine_t *engine, const chol_transp
   long long info = 0;
   int rc = dist.setup();
   if (!rc) rc = dist.factorize(lookahead != 0, &info);
+  if (rc) (void)dist.end();
   g_last_issue_us_per_wave = dist.issue_us / (eng.nt > 0 ? eng.nt : 1);
   g_last_sends = dist.nsend, g_last_recvs = dist.nrecv, g_last_bytes = dist.bytes_sent;
   if (rc) return rc;
