@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
         L.orc_plgsy_entry.restype = C.c_double
         L.orc_plgsy_matrix.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_plgsy_tiles.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
+        L.orc_plgsy_tiles_lower.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_dgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                    C.c_double, _dp, C.c_int]
         L.orc_dsyrk_ln.argtypes = [C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_double, _dp, C.c_int]
@@ -133,6 +134,14 @@ def plgsy_tiles(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- tile ops
+def plgsy_tiles_lower(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
+    """Tile layout with only the tiles on or below the diagonal filled (the others are zero): the
+    factorisation's input, generated one tile column at a time (fast)."""
+    T = np.zeros(Nb * Nb * B * B, dtype=np.float64)
+    lib().orc_plgsy_tiles_lower(T, Nb, B, float(bump), int(seed))
+    return T
+
+
 def dpotrf(A: np.ndarray) -> tuple[np.ndarray, int]:
     """CHAMELEON_dpotrf_Tile(ChamLower) on one tile (W2:238). Returns (tile, info)."""
     A = np.array(A, dtype=np.float64, order="F", copy=True)
