@@ -168,3 +168,18 @@ def test_fp32_ops_match_fp64_to_single_precision():
     C0 = np.asfortranarray(rng.standard_normal((n, n)))
     assert np.abs(orc.sgemm(X, M, C0) - orc.dgemm(X, M, C0)).max() < 1e-3
     assert np.abs(np.tril(orc.ssyrk(X, C0)) - np.tril(orc.dsyrk(X, C0))).max() < 1e-3
+
+
+def test_fast_lower_tile_generator_matches_the_entrywise_one():
+    """bench.py's CPU baseline input: orc_plgsy_tiles_lower walks the LCG down each tile column (one jump per
+    column) -- bit-identical to the entry-by-entry generator on every tile the factorisation reads."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    Nb, B = 5, 48
+    a, b = orc.plgsy_tiles(Nb, B, 240.0, 42), orc.plgsy_tiles_lower(Nb, B, 240.0, 42)
+    for J in range(Nb):
+        for I in range(Nb):
+            ta, tb = (x[(I + J * Nb) * B * B:(I + J * Nb + 1) * B * B] for x in (a, b))
+            assert np.array_equal(ta.view(np.uint64), tb.view(np.uint64)) if I >= J else not tb.any()
