@@ -99,6 +99,12 @@ def _worker_cabi(rank, world, port, N, B, q, bad):
     tr.install()
     info = eng.potrf_tile()  # CHAMELEON_dpotrf_Tile(ChamLower, descriptor with p*q > 1): the C++ wave loop
     stats = dd.dist_last_stats()
+    # the verification step bench.py takes after a multi-GPU run: the factor gathered on rank 0, residual there
+    from dense_linear_app_amd import chameleon as ch
+
+    full = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, 1, 1) if rank == 0 else None
+    dd.gather_lower(eng.desc, full, 0)
+    stats["residual"] = ch.residual_plgsy(full, float(N), 42) if (rank == 0 and bad is None) else None
     tiles = {}
     for I in range(eng.nt):
         for J in range(I + 1):
@@ -138,6 +144,7 @@ def test_potrf_tile_on_a_pxq_descriptor(world, bad, orc):
     for rank, info, tiles, stats in got:
         assert info == 0
         assert stats["sends"] > 0 and stats["issue_us_per_wave"] > 0
+        assert (stats["residual"] <= 1e-13) if rank == 0 else stats["residual"] is None
         for (I, J), t in tiles.items():
             ref = Lref[I * B:(I + 1) * B, J * B:(J + 1) * B]
             d = np.tril(t) - np.tril(ref) if I == J else t - ref
