@@ -24,6 +24,9 @@ extern "C" void chol_internal_dist_finalize(void);
 
 namespace {
 
+constexpr int SEM_WAVES = 2048;             // tile columns the device-side counters cover
+constexpr int SEM_INTS = SEM_WAVES * 4 * 32;  // three counters per wave (four slots), each on a 128-byte line of its own
+
 struct Ctx {
   bool inited = false;
   int device = -1;
@@ -33,6 +36,7 @@ struct Ctx {
   size_t winv_bytes = 0;
   int *d_info = nullptr;
   int *d_ytab = nullptr;  // per-CU yield requests (kernels.hip: cooperative CU hand-over)
+  int *d_sem = nullptr;   // device-side dependency counters of the panel chain (kernels.hip: sem_wait), or null
   double *d_acc = nullptr;
   void *stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_bytes[3] = {0, 0, 0};
@@ -199,7 +203,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   const int nbm = mb / MACRO;
   enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_PER_WAVE };
   enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
-  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm + 1);
+  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + 2 * nbm + 1);
   if (rc) return rc;
   auto ev = [&](int k, int which) { return g.events[(size_t)E_PER_WAVE * k + which]; };
   hipEvent_t *fixed = &g.events[(size_t)E_PER_WAVE * nt];
@@ -218,9 +222,19 @@ int potrf_full_device(chol_desc *d, void *base) {
   // (the hops it removes were overlapped work, not latency); CHOLMI_CHAIN_INSTREAM=1 enables it.
   static const bool chain_enabled = getenv("CHOLMI_CHAIN_INSTREAM") && atoi(getenv("CHOLMI_CHAIN_INSTREAM")) != 0;
   static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
+  static const bool syrk_pipe = !(getenv("CHOLMI_SYRK_PIPE") && atoi(getenv("CHOLMI_SYRK_PIPE")) == 0);
+  const bool trsm_fused_on = cholmi::g_trsm_fused_min > 0;
   int open_bracket = -1;                      // odd wave whose profiling bracket is still open
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
+  // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): counters
+  // (k, 0) = POTRF(k)'s last diagonal block is done, (k, 1) = head-tile workgroups of TRSM(k)'s last step,
+  // (k, 2) = workgroups of the last SYRK slice on tile (k+1,k+1)
+  const bool flags = g.d_sem && nt <= SEM_WAVES && concurrent;
+  if (flags) HIPCHECK(hipMemsetAsync(g.d_sem, 0, (size_t)nt * 4 * 32 * sizeof(int), g.s_main));
+  auto sem = [&](int k, int which) { return g.d_sem + ((size_t)4 * k + which) * 32; };
+  const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
+  int wait_target = 0;
   HIPCHECK(hipEventRecord(fixed[F_START], g.s_main));
   HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_START], 0));
   HIPCHECK(hipStreamWaitEvent(g.s_u1, fixed[F_START], 0));
@@ -229,11 +243,11 @@ int potrf_full_device(chol_desc *d, void *base) {
   double upd_flops = 0;
   int upd_launches = 0;
   for (int k = 0; k < nt; ++k) {
-    HIPCHECK(hipEventRecord(fixed[F_WAVE], g.s_panel));  // s_panel has waited for the SYRK on (k,k) by panel k-1
     // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream, which
     // also needs the rest of column k updated by panel k-1  (C2:510-535)
     T *lkk = M + ((long)k + (long)k * nt) * bsiz;
-    HIPCHECK(hipStreamWaitEvent(g.s_trsm, fixed[F_WAVE], 0));
+    // (s_trsm needs no event for the start of the wave: its first step waits for the event recorded on
+    // s_panel behind the first diagonal-block step, and a record on s_panel costs the chain ~7 us)
     if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev(k - 1, E_U1R), 0));
     // chain: this wave is about as long as its panel chain -- keep the chain's own launches on s_panel
     const double mrem = nt - 1 - k;
@@ -242,15 +256,47 @@ int potrf_full_device(chol_desc *d, void *base) {
     // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite
     // its set while TRSM(k) still reads the other
     T *winv_k = winv + (size_t)(k & 1) * (g.winv_bytes / sizeof(T));
+    if ((k & 1) == 0) {
+      const double m = nt - 1 - k;
+      paired = mb <= pair_max_mb && k + 2 < nt &&
+               m * (m + 1) / 2 * (2.0 * b3 / 65e12) >= pair_fac * (nbm * 130e-6 * 1.5);
+    }
+    // Plain (unpaired) wave whose panel chain is (nearly) critical: the SYRK on tile (k+1,k+1) follows
+    // the head tile's TRSM steps slice by slice and the chain's cross-stream edges are device-side
+    // counters (SyrkPipe).
+    const bool plain_yield = mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < yfac * (nbm * 130e-6 * 1.5);
+    hipStream_t su_k = concurrent ? g.s_u1 : g.s_main;
+    const bool pipe = syrk_pipe && flags && !paired && !chain && k + 1 < nt && cholmi::g_intile_small &&
+                      !trsm_fused_on && (plain_yield || getenv("CHOLMI_SPLIT_U1") != nullptr);
+    SyrkPipe sy;
+    if (pipe) {
+      // the tile's earlier writers: U2(k-1), whose range includes column k+1 (or, behind the paired
+      // phase, the column launches of the last pair, which precede this on s_u1 / are joined here)
+      if (concurrent && k > 0) HIPCHECK(hipStreamWaitEvent(su_k, ev(k - 1, E_U2), 0));
+      if (!concurrent && cols_pending) HIPCHECK(hipStreamWaitEvent(su_k, fixed[F_COLS], 0));
+      sy.c = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
+      sy.su = su_k;
+      sy.ev_x = ev_steps + nbm + 1;
+      sy.sem_diag = sem(k, 0);
+      sy.sem_head = sem(k, 1);
+      sy.sem_done = sem(k, 2);
+    }
     launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv_k, g.d_info, k * mb, lkk + bsiz, bsiz,
-                              nt - 1 - k, fixed[F_HEAD], chain, k > 0 ? ev(k - 1, E_U1R) : nullptr);
+                              nt - 1 - k, fixed[F_HEAD], chain, k > 0 ? ev(k - 1, E_U1R) : nullptr,
+                              pipe ? &sy : nullptr, wait_sem, wait_target);
+    // with device-side edges s_panel waits for no event between waves: POTRF(k+1)'s first step polls the
+    // last slice's counter, which also stands behind TRSM(k) (same stream, earlier), so POTRF(k+2) may
+    // reuse TRSM(k)'s workspace
+    const bool by_flags = pipe;
+    wait_sem = by_flags ? sem(k, 2) : nullptr;
+    wait_target = (mb / 64) * (mb / 64 + 1) / 2;
     // TRSM(k) complete = panel k ready (s_trsm has waited for every POTRF step, and for the head tile's
     // in-stream step in chain mode).
     HIPCHECK(hipEventRecord(ev(k, E_PANEL), g.s_trsm));
     // In chain mode s_panel does not wait for it: POTRF(k+1) needs the SYRK only, and TRSM(k) is over
     // before POTRF(k+2) reuses its workspace (the head tile's last step of TRSM(k+1) waits for the
     // earlier ones, which follow TRSM(k) in stream order -- with more than one step per tile).
-    if (!chain || nbm == 1) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_PANEL), 0));
+    if ((!chain || nbm == 1) && !by_flags) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_PANEL), 0));
     if (k + 1 >= nt) break;
     // trailing update (C2:540-560)
     auto panel_ref = [&](int kk) {
@@ -261,11 +307,6 @@ int potrf_full_device(chol_desc *d, void *base) {
       return pr;
     };
     const PanelRef pan = panel_ref(k);
-    if ((k & 1) == 0) {
-      const double m = nt - 1 - k;
-      paired = mb <= pair_max_mb && k + 2 < nt &&
-               m * (m + 1) / 2 * (2.0 * b3 / 65e12) >= pair_fac * (nbm * 130e-6 * 1.5);
-    }
     if (paired) {
       // Panels in pairs (k-1, k), k odd: the far columns' update by the even panel is deferred and
       // applied together with the odd one in ONE pass of twice the K (k_trail_update, npan = 2).
@@ -375,7 +416,8 @@ int potrf_full_device(chol_desc *d, void *base) {
       HIPCHECK(hipEventRecord(ev(k, E_U1D), g.s_panel));
     }
     // the SYRK on (k+1,k+1) needs the head tile L(k+1,k) only; everything else the whole panel
-    HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small && !syrk_instream) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
+    if (!pipe)
+      HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small && !syrk_instream) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
     if (cols_pending) {  // first plain wave after the paired phase: Cb of the last pair wrote column k+2
       HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
       cols_pending = false;
@@ -390,8 +432,8 @@ int potrf_full_device(chol_desc *d, void *base) {
     if (split) {
       // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
       // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
-      if (syrk_instream) {
-        // (done above, on s_panel)
+      if (syrk_instream || pipe) {
+        // (done above: on s_panel / by launch_panel_pipelined)
       } else if (cholmi::g_intile_small) {
         launch_diag_syrk<T>(su, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
                             M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
@@ -412,7 +454,7 @@ int potrf_full_device(chol_desc *d, void *base) {
       HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
     }
-    if (!syrk_instream) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
+    if (!syrk_instream && !by_flags) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
     if (concurrent && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
     if (r2.na + r2.nb > 0) {
       launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
@@ -697,6 +739,31 @@ int chol_init(int ncpu, int ngpu) {
       cholmi::g_ytab = g.d_ytab;
     }
   }
+  {
+    // Device-side edges of the panel chain: usable only if a kernel polling on one of the two panel
+    // streams does not keep the other from running (streams that share a hardware queue would
+    // deadlock until the poll's bound).  Probed once, both ways, consumer launched first.
+    const char *e = getenv("CHOLMI_DEVICE_FLAGS");
+    if (!e || atoi(e) != 0) {
+      HIPCHECK(hipMalloc(&g.d_sem, SEM_INTS * sizeof(int)));
+      HIPCHECK(hipMemset(g.d_sem, 0, SEM_INTS * sizeof(int)));
+      bool ok = true;
+      const hipStream_t pairs[4][2] = {{g.s_trsm, g.s_panel}, {g.s_u1, g.s_trsm}, {g.s_panel, g.s_u1}, {g.s_panel, g.s_trsm}};
+      for (int t = 0; t < 4 && ok; ++t) {  // {consumer, producer}: the three edges of SyrkPipe, and sp / st the other way
+        int *sem = g.d_sem + 64 * t, *res = g.d_sem + 64 * t + 32;
+        cholmi::launch_sem_probe(pairs[t][0], pairs[t][1], sem, res);
+        HIPCHECK(hipStreamSynchronize(pairs[t][0]));
+        HIPCHECK(hipStreamSynchronize(pairs[t][1]));
+        int r = 0;
+        HIPCHECK(hipMemcpy(&r, res, sizeof(int), hipMemcpyDeviceToHost));
+        ok = (r == 1);
+      }
+      if (!ok) {
+        (void)hipFree(g.d_sem);
+        g.d_sem = nullptr;
+      }
+    }
+  }
   g.inited = true;
   return 0;
 }
@@ -718,6 +785,8 @@ int chol_finalize(void) {
   (void)hipFree(g.d_acc);
   if (g.d_ytab) (void)hipFree(g.d_ytab);
   g.d_ytab = nullptr;
+  if (g.d_sem) (void)hipFree(g.d_sem);
+  g.d_sem = nullptr;
   cholmi::g_ytab = nullptr;
   (void)hipStreamDestroy(g.s_main);
   (void)hipStreamDestroy(g.s_panel);

@@ -92,10 +92,30 @@ void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 // TRSM step runs on sp itself (no cross-stream hop on the critical chain); st is made to wait for it, so an
 // event the caller records on st afterwards stands for the whole panel.  ev_col (chain mode): the event behind which
 // the panel's tiles carry every earlier update -- what st has been made to wait for by the caller.
+// chol_init's probe: the consumer kernel goes first, polls *sem (zeroed) for <= ~20 ms and writes 1 (seen) or
+// 2 (gave up) to *result; the producer kernel raises *sem
+void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result);
+
+// The chain-bound form of a wave (device-side edges, kernels.hip: sem_wait).  The SYRK on the next diagonal
+// tile, C(k+1,k+1) -= L(k+1,k) L(k+1,k)^T, is cut into the K = 128 slices of the head tile's block columns
+// and issued on `su` as the TRSM steps deliver them; between the POTRF's last diagonal-block step and the
+// next POTRF's first there is no stream operation at all:
+//   POTRF(k) last step  --sem_diag-->  last TRSM step  --sem_head-->  last slice  --sem_done-->  POTRF(k+1)
+// each consumer launched ahead of time on its own stream and polling its counter.
+struct SyrkPipe {
+  void *c;           // tile (k+1,k+1)
+  hipStream_t su;    // has already waited for the earlier writers of that tile
+  hipEvent_t *ev_x;  // nbm events (scratch)
+  int *sem_diag;     // raised by the POTRF's last diagonal-block step, polled by the last TRSM step's solve
+  int *sem_head;     // counts the head tile's workgroups of that solve, polled by the last slice
+  int *sem_done;     // counts the last slice's workgroups (n (n + 1) / 2, n = mb / 64), polled by POTRF(k+1)
+};
+
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles,
-                            hipEvent_t ev_head = nullptr, bool chain = false, hipEvent_t ev_col = nullptr);
+                            hipEvent_t ev_head = nullptr, bool chain = false, hipEvent_t ev_col = nullptr,
+                            const SyrkPipe *sy = nullptr, const int *wait_sem = nullptr, int wait_target = 0);
 
 // winv from an already factored tile
 template <typename T>

@@ -194,6 +194,63 @@ __device__ __forceinline__ void yield_to_guest(const int *slot) {
 }
 
 // ------------------------------------------------------------------------------
+// Device-side dependencies for the panel chain.  A dependency that crosses HIP streams costs 10-15 us of
+// wake-up on this runtime (scripts/exp/event_cost.hip: 10.5 us alone, 15 us beside other event traffic,
+// against 0.9 us for a kernel that is already resident and polls a word), and a chain-bound wave pays it
+// twice: POTRF's last diagonal block -> the panel's last TRSM step, and the last SYRK slice -> the next
+// POTRF.  On those two edges the consumer kernel is therefore launched WITHOUT a stream wait and polls a
+// counter its producer raises: one lane, relaxed agent-scope loads, then an agent-scope acquire, the
+// wait for it and the workgroup barrier before any other lane loads (the consumer recipe of
+// MI355X_MICROARCH.md); the producer: every wave's stores drained by the workgroup barrier, an
+// agent-scope release by one lane, then the counter.  The polls are bounded (~seconds): a consumer that
+// gives up reports INT_MAX through `fail` -- a loud error, never a hang -- and chol_init checks on the
+// library's own streams that a polling kernel does not block its producer's stream (streams sharing a
+// hardware queue would) before the scheme is used at all.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ void sem_wait(const int *sem, int target, int *fail) {
+  if (sem) {
+    if (threadIdx.x == 0) {
+      bool ok = false;
+      for (int i = 0; i < (1 << 21); ++i) {
+        if (__hip_atomic_load(sem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+          ok = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!ok && fail) atomicExch(fail, 0x7fffffff);
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void sem_signal(int *sem) {
+  if (sem) {
+    __syncthreads();  // (drains every wave's stores: s_waitcnt vmcnt(0) ahead of the barrier)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// chol_init's check (see above): the consumer is launched first and polls for at most ~20 ms
+__global__ void k_sem_probe_wait(const int *sem, int *result) {
+  int ok = 2;
+  for (int i = 0; i < 20000; ++i) {
+    if (__hip_atomic_load(sem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 1) {
+      ok = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *result = ok;
+}
+__global__ void k_sem_probe_set(int *sem) { sem_signal(sem); }
+
+// ------------------------------------------------------------------------------
 // "Paired" form of the NT core (trailing update): fragment rows are interleaved so that
 // lane i of a 16-lane group owns EPL = 16 B / sizeof(T) CONSECUTIVE rows (fp64: rows 2i,
 // 2i+1 of a 32-row group; fp32: rows 4i..4i+3 of the 64-row group).  One ds_read_b128
@@ -834,8 +891,11 @@ __global__ __launch_bounds__(512, 4) void k_trail_update_w8f(LocalMat C, const i
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int mb, int nbm, int r0,
                                                         int s, const T *__restrict__ winv, T alpha,
-                                                        int *ytab) {
+                                                        int *ytab, const int *wait_sem = nullptr,
+                                                        int wait_target = 0, int *fail = nullptr,
+                                                        int *head_sem = nullptr) {
   __shared__ SmemP<T> sm;
+  sem_wait(wait_sem, wait_target, fail);
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nr = nbm - r0;
@@ -847,6 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
   nt_kloop_paired<T, true>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
   nt_epilogue_paired<T>(Ap, mb, acc, alpha, T(0), false);
   guest.leave();
+  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: nr counts)
 }
 
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
@@ -1130,9 +1191,12 @@ __device__ __forceinline__ void small_mma(const SmallImg<T, RA> &ia, const Small
 // them before it writes).  In-tile step: one tile, r0 = s+1; panel TRSM step: all panel tiles, r0 = 0.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int mb, int nbm, int r0, int s,
-                                                        const T *__restrict__ winv, T alpha, int *ytab) {
+                                                        const T *__restrict__ winv, T alpha, int *ytab,
+                                                        const int *wait_sem = nullptr, int wait_target = 0,
+                                                        int *fail = nullptr, int *head_sem = nullptr) {
   __shared__ SmallImg<T, 32> ia;
   __shared__ SmallImg<T, MACRO> ib;
+  sem_wait(wait_sem, wait_target, fail);
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);
   const int per_tile = 4 * (nbm - r0);
@@ -1169,6 +1233,7 @@ __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int
       for (int r = 0; r < 4; ++r)
         Ap[16 * a + lo + (long)(32 * w + 16 * b + Tr<T>::drow(lane, r)) * mb] = alpha * acc[a][b][r];
   guest.leave();
+  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: per_tile counts)
 }
 
 // C(r64, c64) -= A(r64, :) B(c64, :)^T over K columns, for the 64 x 64 blocks on or below the
@@ -1181,10 +1246,13 @@ __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T *__restrict__ A,
                                                         const T *__restrict__ B, long ldab, int K, int *ytab,
-                                                        int full, long zc, long za) {
+                                                        int full, long zc, long za, int *signal_sem = nullptr,
+                                                        const int *wait_sem = nullptr, int wait_target = 0,
+                                                        int *fail = nullptr) {
   __shared__ SmallImg<T, 64> ia, ib;
   const int r64 = blockIdx.x, c64 = blockIdx.y;
   if (!full && c64 > r64) return;
+  sem_wait(wait_sem, wait_target, fail);
   C += blockIdx.z * zc;  // (panel TRSM step: one z per panel tile, B is the diagonal tile for all)
   A += blockIdx.z * za;
   GuestOnCu guest(ytab);
@@ -1227,6 +1295,7 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
         if (!dg || i >= j) Cp[i + (long)j * ldc] -= acc[a][b][r];
       }
   guest.leave();
+  sem_signal(signal_sem);  // (one count per workgroup that has a block: n (n + 1) / 2 of the n x n grid when !full)
 }
 
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
@@ -1839,9 +1908,12 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_potrf_diag(T *A, int ld, T *__restrict__ winv, int *info,
                                                     int info_base, int factor,
-                                                    unsigned long long *dbg, int *ytab) {
+                                                    unsigned long long *dbg, int *ytab,
+                                                    const int *wait_sem = nullptr, int wait_target = 0,
+                                                    int *signal_sem = nullptr) {
   __shared__ DiagLds<T> L;
   __shared__ unsigned long long slot_s;
+  sem_wait(wait_sem, wait_target, info);  // (before the CU is asked to yield: the poll may last a while)
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(3);
   unsigned long long t0 = 0;
@@ -1858,6 +1930,7 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag(T *A, int ld, T *__restri
     ph[-1] = __builtin_amdgcn_s_memrealtime();
   }
   guest.leave();
+  sem_signal(signal_sem);
 }
 
 // ------------------------------------------------------------------------------
@@ -2072,6 +2145,11 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------
+void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result) {
+  k_sem_probe_wait<<<1, 1, 0, consumer>>>(sem, result);
+  k_sem_probe_set<<<1, 64, 0, producer>>>(sem);
+}
+
 int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU hand-over), may be null
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
 int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four waves + register staging, 2..5 eight waves (MODE = variant - 2: bit 0 DMA behind the first MFMAs, bit 1 static priority); fp32 always 0 / 1 (CHOLMI_VARIANT)
@@ -2136,23 +2214,28 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
 // One 128-column step of the panel TRSM over `ntiles` tiles: X[:, st] = A[:, st] Winv_st^T, then
 // A[:, c] -= X[:, st] L(c, st)^T for the block columns c > st.  Few tiles (the late, chain-bound
 // waves): small-block kernels, latency; many tiles: the 128 x 128 NT core, throughput.
+// (returns how many workgroups of the solve belong to the first tile: what head_sem counts up to)
 template <typename T>
-void trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb, int st,
-               T alpha) {
+int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb, int st,
+              T alpha, const int *wait_sem = nullptr, int wait_target = 0, int *fail = nullptr,
+              int *head_sem = nullptr) {
   const int nbm = mb / MACRO, nc = nbm - 1 - st;
   if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
-    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab);
+    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab, wait_sem,
+                                                      wait_target, fail, head_sem);
     if (nc > 0)
       k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
           tiles + (long)(st + 1) * MACRO * mb, mb, tiles + (long)st * MACRO * mb,
           lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz);
-    return;
+    return 4 * nbm;
   }
   // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
   // first update of blocks > 0
-  k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab);
+  k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab,
+                                                wait_sem, wait_target, fail, head_sem);
   if (nc > 0)
     k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab);
+  return nbm;
 }
 
 // C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
@@ -2210,9 +2293,12 @@ void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
-                            bool chain, hipEvent_t ev_col) {
+                            bool chain, hipEvent_t ev_col, const SyrkPipe *sy, const int *wait_sem,
+                            int wait_target) {
   const int nbm = mb / MACRO;
   const bool fused = trsm_fused_applies<T>(ntiles - 1, mb);
+  // (SyrkPipe needs the step-by-step TRSM of the whole panel; the walker does not combine it with the fused form)
+  const bool pipe = sy && !fused && !chain && ntiles > 0;
   const int nstep = fused ? 1 : ntiles;  // tiles that follow the POTRF step by step
   // chain: the wave is as long as its panel chain (late waves, small matrices).  A dependency that
   // crosses streams costs 14-19 us of wake-up latency where one inside a stream costs ~1 us, so the
@@ -2221,7 +2307,8 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
     k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
-                                       d_info, info_base + s * MACRO, 1, g_dbg, g_ytab);
+                                       d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
+                                       wait_target, (s == nbm - 1 && pipe) ? sy->sem_diag : nullptr);
     if (nr > 0) {
       if (g_intile_small) {
         k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab);
@@ -2236,7 +2323,8 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
     if (ntiles <= 0) continue;
     // (recorded behind the in-tile update, not between the solve and the update: an event record
     // between two dependent launches of the chain costs it ~7 us, the TRSM step loses nothing)
-    (void)hipEventRecord(ev[s], sp);
+    const bool by_sem = pipe && s == nbm - 1;  // the last step's solve polls the diagonal block's counter instead
+    if (!by_sem) (void)hipEventRecord(ev[s], sp);
     if (chain && s == nbm - 1) {
       // the head tile's earlier steps (on st, which waited for the panel's column to be up to date);
       // with one step per tile sp itself must wait for that column: ev_col
@@ -2250,18 +2338,34 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       if (nstep > 1) trsm_step<T>(st, tiles + bsiz, bsiz, nstep - 1, lkk, winv, mb, s, T(1));
       if (ev_head) (void)hipStreamWaitEvent(st, ev_head, 0);  // what the caller records on st next covers the head tile
     } else {
-      (void)hipStreamWaitEvent(st, ev[s], 0);
-      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
+      if (!by_sem) (void)hipStreamWaitEvent(st, ev[s], 0);
+      const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), by_sem ? sy->sem_diag : nullptr,
+                                        1, d_info, by_sem ? sy->sem_head : nullptr);
       if (chain && s == nbm - 2) (void)hipEventRecord(ev[nbm], st);
+      if (pipe) {
+        // C(k+1,k+1) -= X_s X_s^T, X = the head tile: on su, behind the event of its TRSM step -- but the
+        // last one behind the step's own counter, with no stream operation between the POTRF's last
+        // diagonal block and the next POTRF's first
+        const T *xs = tiles + (long)s * MACRO * mb;
+        if (s < nbm - 1) {
+          (void)hipEventRecord(sy->ev_x[s], st);
+          (void)hipStreamWaitEvent(sy->su, sy->ev_x[s], 0);
+        }
+        k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, sy->su>>>(
+            reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0, by_sem ? sy->sem_done : nullptr,
+            by_sem ? sy->sem_head : nullptr, head_wgs, d_info);
+      }
     }
   }
   if (ev_head && !(chain && ntiles > 0)) (void)hipEventRecord(ev_head, st);
   if (fused) launch_trsm_fused<T>(st, tiles + bsiz, bsiz, ntiles - 1, lkk, winv, mb);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
-                                             int *, int, double *, long, int, hipEvent_t, bool, hipEvent_t);
+                                             int *, int, double *, long, int, hipEvent_t, bool, hipEvent_t,
+                                             const SyrkPipe *, const int *, int);
 template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
-                                            int, float *, long, int, hipEvent_t, bool, hipEvent_t);
+                                            int, float *, long, int, hipEvent_t, bool, hipEvent_t, const SyrkPipe *,
+                                            const int *, int);
 
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
