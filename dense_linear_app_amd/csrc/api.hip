@@ -24,8 +24,8 @@ extern "C" void chol_internal_dist_finalize(void);
 
 namespace {
 
-constexpr int SEM_WAVES = 2048;             // tile columns the device-side counters cover
-constexpr int SEM_INTS = SEM_WAVES * 4 * 32;  // three counters per wave (four slots), each on a 128-byte line of its own
+constexpr int SEM_SLOTS = 16384;          // device-side counters: 3 mb/128 + 1 per tile column ...
+constexpr int SEM_INTS = SEM_SLOTS * 32;  // ... each on a 128-byte line of its own
 
 struct Ctx {
   bool inited = false;
@@ -203,7 +203,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   const int nbm = mb / MACRO;
   enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_PER_WAVE };
   enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
-  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + 2 * nbm + 1);
+  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm + 1);
   if (rc) return rc;
   auto ev = [&](int k, int which) { return g.events[(size_t)E_PER_WAVE * k + which]; };
   hipEvent_t *fixed = &g.events[(size_t)E_PER_WAVE * nt];
@@ -227,17 +227,18 @@ int potrf_full_device(chol_desc *d, void *base) {
   int open_bracket = -1;                      // odd wave whose profiling bracket is still open
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
-  // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): counters
-  // (k, 0) = POTRF(k)'s last diagonal block is done, (k, 1) = head-tile workgroups of TRSM(k)'s last step,
-  // (k, 2) = workgroups of the last SYRK slice on tile (k+1,k+1)
-  const bool flags = g.d_sem && nt <= SEM_WAVES && concurrent;
-  if (flags) HIPCHECK(hipMemsetAsync(g.d_sem, 0, (size_t)nt * 4 * 32 * sizeof(int), g.s_main));
-  auto sem = [&](int k, int which) { return g.d_sem + ((size_t)4 * k + which) * 32; };
+  // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): 3 nbm + 1
+  // counters per wave, the last one = workgroups of the last SYRK slice on tile (k+1,k+1)
+  const int sem_per_wave = 3 * nbm + 1;
+  const bool flags = g.d_sem && (long)nt * sem_per_wave <= SEM_SLOTS && concurrent;
+  if (flags) HIPCHECK(hipMemsetAsync(g.d_sem, 0, (size_t)nt * sem_per_wave * 32 * sizeof(int), g.s_main));
+  auto sem = [&](int k, int which) { return g.d_sem + ((size_t)sem_per_wave * k + which) * 32; };
   const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
   int wait_target = 0;
   HIPCHECK(hipEventRecord(fixed[F_START], g.s_main));
   HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_START], 0));
   HIPCHECK(hipStreamWaitEvent(g.s_u1, fixed[F_START], 0));
+  HIPCHECK(hipStreamWaitEvent(g.s_trsm, fixed[F_START], 0));  // (its kernels may poll counters zeroed above)
   const LocalMat C = local_mat(d, base);
   const double b3 = (double)mb * mb * mb;
   double upd_flops = 0;
@@ -276,10 +277,7 @@ int potrf_full_device(chol_desc *d, void *base) {
       if (!concurrent && cols_pending) HIPCHECK(hipStreamWaitEvent(su_k, fixed[F_COLS], 0));
       sy.c = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
       sy.su = su_k;
-      sy.ev_x = ev_steps + nbm + 1;
-      sy.sem_diag = sem(k, 0);
-      sy.sem_head = sem(k, 1);
-      sy.sem_done = sem(k, 2);
+      sy.sem = sem(k, 0);
     }
     launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv_k, g.d_info, k * mb, lkk + bsiz, bsiz,
                               nt - 1 - k, fixed[F_HEAD], chain, k > 0 ? ev(k - 1, E_U1R) : nullptr,
@@ -288,7 +286,7 @@ int potrf_full_device(chol_desc *d, void *base) {
     // last slice's counter, which also stands behind TRSM(k) (same stream, earlier), so POTRF(k+2) may
     // reuse TRSM(k)'s workspace
     const bool by_flags = pipe;
-    wait_sem = by_flags ? sem(k, 2) : nullptr;
+    wait_sem = by_flags ? sem(k, 3 * nbm) : nullptr;
     wait_target = (mb / 64) * (mb / 64 + 1) / 2;
     // TRSM(k) complete = panel k ready (s_trsm has waited for every POTRF step, and for the head tile's
     // in-stream step in chain mode).

@@ -98,17 +98,15 @@ void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int 
 
 // The chain-bound form of a wave (device-side edges, kernels.hip: sem_wait).  The SYRK on the next diagonal
 // tile, C(k+1,k+1) -= L(k+1,k) L(k+1,k)^T, is cut into the K = 128 slices of the head tile's block columns
-// and issued on `su` as the TRSM steps deliver them; between the POTRF's last diagonal-block step and the
-// next POTRF's first there is no stream operation at all:
-//   POTRF(k) last step  --sem_diag-->  last TRSM step  --sem_head-->  last slice  --sem_done-->  POTRF(k+1)
-// each consumer launched ahead of time on its own stream and polling its counter.
+// and issued on `su`; the TRSM steps go to the TRSM stream as before -- but every kernel of the three
+// streams is launched ahead of time, without a stream operation, and polls the counter of what it needs:
+//   diagonal-block step s  -->  TRSM step s: solve  -->  slice s          in-tile solve s  -->  TRSM step s: update
+//   last slice  -->  POTRF(k+1)'s first diagonal-block step (launch_panel_pipelined's wait_sem / wait_target)
 struct SyrkPipe {
-  void *c;           // tile (k+1,k+1)
-  hipStream_t su;    // has already waited for the earlier writers of that tile
-  hipEvent_t *ev_x;  // nbm events (scratch)
-  int *sem_diag;     // raised by the POTRF's last diagonal-block step, polled by the last TRSM step's solve
-  int *sem_head;     // counts the head tile's workgroups of that solve, polled by the last slice
-  int *sem_done;     // counts the last slice's workgroups (n (n + 1) / 2, n = mb / 64), polled by POTRF(k+1)
+  void *c;         // tile (k+1,k+1)
+  hipStream_t su;  // has already waited for the earlier writers of that tile
+  int *sem;        // 3 nbm + 1 zeroed counters of this wave, 32 ints (one 128-byte line) apart; the last one
+                   // counts the last slice's workgroups: n (n + 1) / 2, n = mb / 64
 };
 
 template <typename T>

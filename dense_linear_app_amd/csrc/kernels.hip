@@ -913,8 +913,11 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, int mb, int nbm, int s,
-                                                         const T *__restrict__ lkk, T beta, int *ytab) {
+                                                         const T *__restrict__ lkk, T beta, int *ytab,
+                                                         const int *wait_sem = nullptr, int wait_target = 0,
+                                                         int *fail = nullptr) {
   __shared__ SmemP<T> sm;
+  sem_wait(wait_sem, wait_target, fail);
   GuestOnCu guest(ytab);
   __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
   const int nc = nbm - 1 - s;
@@ -2214,27 +2217,38 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
 // One 128-column step of the panel TRSM over `ntiles` tiles: X[:, st] = A[:, st] Winv_st^T, then
 // A[:, c] -= X[:, st] L(c, st)^T for the block columns c > st.  Few tiles (the late, chain-bound
 // waves): small-block kernels, latency; many tiles: the 128 x 128 NT core, throughput.
-// (returns how many workgroups of the solve belong to the first tile: what head_sem counts up to)
+// Device-side edges of one step (sem_wait), all optional: the solve polls `diag` (the diagonal-block step
+// that produced Winv_st; target 1), the update polls `intile` (the workgroups of the in-tile solve that
+// produced L(c, st), c > st), and the solve's workgroups of the FIRST tile count up `head`.
+struct StepSems {
+  const int *diag = nullptr;
+  const int *intile = nullptr;
+  int intile_target = 0;
+  int *head = nullptr;
+  int *fail = nullptr;
+};
+// (returns how many workgroups of the solve belong to the first tile: what `head` counts up to)
 template <typename T>
 int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb, int st,
-              T alpha, const int *wait_sem = nullptr, int wait_target = 0, int *fail = nullptr,
-              int *head_sem = nullptr) {
+              T alpha, const StepSems &sm = StepSems()) {
   const int nbm = mb / MACRO, nc = nbm - 1 - st;
   if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
-    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab, wait_sem,
-                                                      wait_target, fail, head_sem);
+    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab, sm.diag, 1,
+                                                      sm.fail, sm.head);
     if (nc > 0)
       k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
           tiles + (long)(st + 1) * MACRO * mb, mb, tiles + (long)st * MACRO * mb,
-          lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz);
+          lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz, nullptr, sm.intile,
+          sm.intile_target, sm.fail);
     return 4 * nbm;
   }
   // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
   // first update of blocks > 0
   k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab,
-                                                wait_sem, wait_target, fail, head_sem);
+                                                sm.diag, 1, sm.fail, sm.head);
   if (nc > 0)
-    k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab);
+    k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab,
+                                                        sm.intile, sm.intile_target, sm.fail);
   return nbm;
 }
 
@@ -2304,14 +2318,18 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
   // crosses streams costs 14-19 us of wake-up latency where one inside a stream costs ~1 us, so the
   // chain's own work -- the head tile's last TRSM step (the earlier ones ran beside the POTRF) -- stays
   // on sp; the caller does the same with the SYRK on the next diagonal tile.
+  // pipe: counters of this wave, one 128-byte slot each -- D[s] the diagonal-block step s, I[s] the in-tile
+  // solve of step s (4 nr workgroups), H[s] the head tile's workgroups of TRSM step s, then `done`
+  auto slot = [&](int i) { return sy->sem + 32 * i; };
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
     k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
                                        d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
-                                       wait_target, (s == nbm - 1 && pipe) ? sy->sem_diag : nullptr);
+                                       wait_target, pipe ? slot(s) : nullptr);
     if (nr > 0) {
       if (g_intile_small) {
-        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab);
+        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
+                                                 pipe ? slot(nbm + s) : nullptr);
         T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
         const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
         k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
@@ -2321,10 +2339,25 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       }
     }
     if (ntiles <= 0) continue;
+    if (pipe) {
+      // No stream operation anywhere on the chain: TRSM step s (on st) and slice s of the SYRK on tile
+      // (k+1,k+1) (on su; X = the head tile, C -= X_s X_s^T) are launched ahead of time and poll.
+      StepSems ss;
+      ss.diag = slot(s);
+      ss.intile = slot(nbm + s);
+      ss.intile_target = 4 * nr;
+      ss.head = slot(2 * nbm + s);
+      ss.fail = d_info;
+      const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
+      const T *xs = tiles + (long)s * MACRO * mb;
+      k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, sy->su>>>(
+          reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0, s == nbm - 1 ? slot(3 * nbm) : nullptr,
+          slot(2 * nbm + s), head_wgs, d_info);
+      continue;
+    }
     // (recorded behind the in-tile update, not between the solve and the update: an event record
     // between two dependent launches of the chain costs it ~7 us, the TRSM step loses nothing)
-    const bool by_sem = pipe && s == nbm - 1;  // the last step's solve polls the diagonal block's counter instead
-    if (!by_sem) (void)hipEventRecord(ev[s], sp);
+    (void)hipEventRecord(ev[s], sp);
     if (chain && s == nbm - 1) {
       // the head tile's earlier steps (on st, which waited for the panel's column to be up to date);
       // with one step per tile sp itself must wait for that column: ev_col
@@ -2338,23 +2371,9 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       if (nstep > 1) trsm_step<T>(st, tiles + bsiz, bsiz, nstep - 1, lkk, winv, mb, s, T(1));
       if (ev_head) (void)hipStreamWaitEvent(st, ev_head, 0);  // what the caller records on st next covers the head tile
     } else {
-      if (!by_sem) (void)hipStreamWaitEvent(st, ev[s], 0);
-      const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), by_sem ? sy->sem_diag : nullptr,
-                                        1, d_info, by_sem ? sy->sem_head : nullptr);
+      (void)hipStreamWaitEvent(st, ev[s], 0);
+      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
       if (chain && s == nbm - 2) (void)hipEventRecord(ev[nbm], st);
-      if (pipe) {
-        // C(k+1,k+1) -= X_s X_s^T, X = the head tile: on su, behind the event of its TRSM step -- but the
-        // last one behind the step's own counter, with no stream operation between the POTRF's last
-        // diagonal block and the next POTRF's first
-        const T *xs = tiles + (long)s * MACRO * mb;
-        if (s < nbm - 1) {
-          (void)hipEventRecord(sy->ev_x[s], st);
-          (void)hipStreamWaitEvent(sy->su, sy->ev_x[s], 0);
-        }
-        k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, sy->su>>>(
-            reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0, by_sem ? sy->sem_done : nullptr,
-            by_sem ? sy->sem_head : nullptr, head_wgs, d_info);
-      }
     }
   }
   if (ev_head && !(chain && ntiles > 0)) (void)hipEventRecord(ev_head, st);
