@@ -224,6 +224,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
   static const bool syrk_pipe = !(getenv("CHOLMI_SYRK_PIPE") && atoi(getenv("CHOLMI_SYRK_PIPE")) == 0);
   const bool trsm_fused_on = cholmi::g_trsm_fused_min > 0;
+  static const double pipe_fac = getenv("CHOLMI_PIPE_FACTOR") ? atof(getenv("CHOLMI_PIPE_FACTOR")) : 0.7;
   int open_bracket = -1;                      // odd wave whose profiling bracket is still open
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
@@ -267,8 +268,11 @@ int potrf_full_device(chol_desc *d, void *base) {
     // counters (SyrkPipe).
     const bool plain_yield = mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < yfac * (nbm * 130e-6 * 1.5);
     hipStream_t su_k = concurrent ? g.s_u1 : g.s_main;
+    // (only while the update is shorter than about a panel chain: the polling workgroups hold CU slots the
+    // update would otherwise use -- measured +10 ... +20 % on the waves between pipe_fac and the yield threshold)
+    const bool chain_bound = mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < pipe_fac * (nbm * 130e-6 * 1.5);
     const bool pipe = syrk_pipe && flags && !paired && !chain && k + 1 < nt && cholmi::g_intile_small &&
-                      !trsm_fused_on && (plain_yield || getenv("CHOLMI_SPLIT_U1") != nullptr);
+                      !trsm_fused_on && plain_yield && chain_bound;
     SyrkPipe sy;
     if (pipe) {
       // the tile's earlier writers: U2(k-1), whose range includes column k+1 (or, behind the paired
