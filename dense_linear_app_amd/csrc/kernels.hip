@@ -1255,11 +1255,8 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
   __shared__ SmallImg<T, 64> ia, ib;
   const int r64 = blockIdx.x, c64 = blockIdx.y;
   if (!full && c64 > r64) return;
-  sem_wait(wait_sem, wait_target, fail);
   C += blockIdx.z * zc;  // (panel TRSM step: one z per panel tile, B is the diagonal tile for all)
   A += blockIdx.z * za;
-  GuestOnCu guest(ytab);
-  __builtin_amdgcn_s_setprio(2);
   const T *Ap = A + 64 * r64;
   const T *Bp = B + 64 * c64;
   T *Cp = C + 64 * r64 + 64 * c64 * ldc;
@@ -1267,12 +1264,23 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
   const int i0 = 32 * (w & 1), j0 = 32 * (w >> 1);
   T ra[64 * SK / 256], rb[64 * SK / 256];
   typename Tr<T>::acc_t acc[2][2];
+  // C up front (nobody else writes this block meanwhile): its load latency -- a cold miss, the block was last
+  // written a step or a wave ago -- is then hidden behind the polls and the K loop instead of ending the kernel
+  T cv[2][2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+      for (int r = 0; r < 4; ++r) {
+        acc[a][b][r] = T(0);
+        cv[a][b][r] = Cp[(i0 + 16 * a + lo) + (long)(j0 + 16 * b + Tr<T>::drow(lane, r)) * ldc];
+      }
+  // (what is polled for is the producer of A / B; the block of C was last written by an earlier launch of
+  // this stream, or before the launch that raised an earlier counter of the chain)
+  sem_wait(wait_sem, wait_target, fail);
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
   small_gload<T, 64>(Ap, (int)ldab, 0, ra);
   small_gload<T, 64>(Bp, (int)ldab, 0, rb);
   const int nph = K / SK;
@@ -1295,7 +1303,7 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + 16 * a + lo, j = j0 + 16 * b + Tr<T>::drow(lane, r);
-        if (!dg || i >= j) Cp[i + (long)j * ldc] -= acc[a][b][r];
+        if (!dg || i >= j) Cp[i + (long)j * ldc] = cv[a][b][r] - acc[a][b][r];
       }
   guest.leave();
   sem_signal(signal_sem);  // (one count per workgroup that has a block: n (n + 1) / 2 of the n x n grid when !full)
@@ -2332,6 +2340,8 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                                  pipe ? slot(nbm + s) : nullptr);
         T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
         const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
+        // (launching this one ahead of time too -- on st, polling the in-tile solve's counter, the next
+        // diagonal-block step polling its own -- measured -1 ... -5 %: it queues behind the previous TRSM step)
         k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
       } else {
         k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);

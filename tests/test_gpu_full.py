@@ -306,7 +306,11 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
 
 @pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_U1_CONCURRENT": "0"},
                                  {"CHOLMI_PAIR_MAX_MB": "0", "CHOLMI_VARIANT": "0"}, {"CHOLMI_TRSM_FUSED_MIN": "1"},
-                                 {"CHOLMI_CHAIN_INSTREAM": "1", "CHOLMI_PAIR_FACTOR": "0"}])
+                                 {"CHOLMI_CHAIN_INSTREAM": "1", "CHOLMI_PAIR_FACTOR": "0"},
+                                 # the chain-bound form (device-side counters): off (events only), from the
+                                 # first wave on, and entered late (event-linked waves first, then counters)
+                                 {"CHOLMI_DEVICE_FLAGS": "0"}, {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"},
+                                 {"CHOLMI_PIPE_FACTOR": "0.02"}])
 def test_walker_schedule_variants_match_the_oracle(env, orc):
     """The walker picks its schedule by size (two panels per pass only while a wave's update is long, and so
     on), so at oracle-sized problems the default run never enters some of them.  Each variant forced through
