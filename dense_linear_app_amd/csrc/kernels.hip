@@ -1428,15 +1428,19 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   {
     const int a = g0 + H + o;
 #pragma unroll
-    for (int bb = 0; bb < H; ++bb) {
-      const int b = g0 + bb;
+    for (int bb = 0; bb < H; ++bb)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) acc[bb][reg] = T(0);
-      for (int c = b; c < g0 + H; ++c) {
-        const T *Sec = (c == b) ? Wd[c] : S + db_off(c, b);
-        mm16<T>(acc[bb], S + db_off(a, c), 1, DB_LD, Sec, 1, (c == b) ? 16 : DB_LD, false);
+    // term t of every product in turn (each accumulator still sums over c ascending): the H chains are
+    // independent and interleave, where one product after the other left the wave waiting for its own MFMAs
+#pragma unroll
+    for (int t = 0; t < H; ++t)
+#pragma unroll
+      for (int bb = 0; bb < H - t; ++bb) {
+        const int b = g0 + bb, c = b + t;
+        const T *Sec = (t == 0) ? Wd[c] : S + db_off(c, b);
+        mm16<T>(acc[bb], S + db_off(a, c), 1, DB_LD, Sec, 1, (t == 0) ? 16 : DB_LD, false);
       }
-    }
 #pragma unroll
     for (int bb = 0; bb < H; ++bb) {
       T *Cb = S + db_off(a, g0 + bb);
@@ -1448,15 +1452,17 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   {
     const int b = g0 + o;
 #pragma unroll
-    for (int aa = 0; aa < H; ++aa) {
-      const int a = g0 + H + aa;
+    for (int aa = 0; aa < H; ++aa)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) acc[aa][reg] = T(0);
-      for (int c = g0 + H; c <= a; ++c) {
-        const T *Fp = (c == a) ? Wd[a] : S + db_off(a, c);
-        mm16<T>(acc[aa], Fp, 1, (c == a) ? 16 : DB_LD, S + db_off(c, b), 1, DB_LD, true);
+#pragma unroll
+    for (int t = 0; t < H; ++t)
+#pragma unroll
+      for (int aa = t; aa < H; ++aa) {  // (product aa has terms c = g0 + H .. a, i.e. t = 0 .. aa)
+        const int a = g0 + H + aa, c = g0 + H + t;
+        const T *Fp = (t == aa) ? Wd[a] : S + db_off(a, c);
+        mm16<T>(acc[aa], Fp, 1, (t == aa) ? 16 : DB_LD, S + db_off(c, b), 1, DB_LD, true);
       }
-    }
 #pragma unroll
     for (int aa = 0; aa < H; ++aa) {
       T *Cb = S + db_off(g0 + H + aa, b);
@@ -1827,20 +1833,53 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       }
       tA += PH_NOW() - tl;
       tl = PH_NOW();
-      // ---- phase B: S(r,c) -= X(r,p) X(c,p)^T for 16x16 blocks p < c <= r
-      int bidx = 0;
-      for (int c = p + 1; c < NP; ++c)
-        for (int r = c; r < NP; ++r, ++bidx) {
-          if ((bidx & 3) != w) continue;
-          typename Tr<T>::acc_t acc;
-          T *Cb = S + db_off(r, c);
+      // ---- phase B: S(r,c) -= X(r,p) X(c,p)^T for 16x16 blocks p < c <= r, dealt round-robin to the
+      // four waves.  A wave takes its blocks two at a time: one block is a chain of LDS reads, four
+      // dependent MFMAs and LDS writes (~500 cycles of latency for ~256 of issue), two independent ones
+      // interleave.
+      {
+        const int nblk = (NP - 1 - p) * (NP - p) / 2;
+        auto block_of = [&](int idx, int &r, int &c) {  // idx-th block in column-major order of the trailing part
+          c = p + 1;
+          int left = idx, len = NP - 1 - p;
+          while (left >= len) {
+            left -= len;
+            --len;
+            ++c;
+          }
+          r = c + left;
+        };
+        for (int i0 = w; i0 < nblk; i0 += 8) {
+          const int i1 = i0 + 4;
+          const bool two = i1 < nblk;
+          int r0, c0, r1, c1;
+          block_of(i0, r0, c0);
+          block_of(two ? i1 : i0, r1, c1);
+          typename Tr<T>::acc_t acc0, acc1;
+          T *Cb0 = S + db_off(r0, c0), *Cb1 = S + db_off(r1, c1);
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) acc[reg] = Cb[Tr<T>::drow(lane, reg) + lo * DB_LD];
+          for (int reg = 0; reg < 4; ++reg) {
+            acc0[reg] = Cb0[Tr<T>::drow(lane, reg) + lo * DB_LD];
+            acc1[reg] = Cb1[Tr<T>::drow(lane, reg) + lo * DB_LD];
+          }
           // D[i][j] = sum_k X(r)[i][k] * X(c)[j][k]
-          mm16<T>(acc, S + db_off(r, p), 1, DB_LD, S + db_off(c, p), DB_LD, 1, true);
+          const T *F0 = S + db_off(r0, p), *G0 = S + db_off(c0, p), *F1 = S + db_off(r1, p), *G1 = S + db_off(c1, p);
+          const int hi = lane >> 4;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc[reg];
+          for (int q = 0; q < 4; ++q) {
+            const T f0 = -F0[lo + (4 * q + hi) * DB_LD], g0 = G0[(4 * q + hi) * DB_LD + lo];
+            const T f1 = -F1[lo + (4 * q + hi) * DB_LD], g1 = G1[(4 * q + hi) * DB_LD + lo];
+            acc0 = Tr<T>::mfma(f0, g0, acc0);
+            acc1 = Tr<T>::mfma(f1, g1, acc1);
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) Cb0[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc0[reg];
+          if (two) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Cb1[Tr<T>::drow(lane, reg) + lo * DB_LD] = acc1[reg];
+          }
         }
+      }
       __syncthreads();
       tB += PH_NOW() - tl;
     }
@@ -1882,7 +1921,9 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       }
     }
   }
-  __syncthreads();
+  // LDS-only barrier: the stores of L to global memory stay in flight across the inversion (a full
+  // __syncthreads() waits for them: ~1.5 us of the chain per diagonal block)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (ph && t == 0) ph[4] = PH_NOW();  // Wd done
 
   // ---- inverse of the whole factor, in place over the strictly-lower blocks
