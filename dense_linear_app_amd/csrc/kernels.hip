@@ -202,7 +202,7 @@ __device__ __forceinline__ void yield_to_guest(const int *slot) {
 // counter its producer raises: one lane, relaxed agent-scope loads, then an agent-scope acquire, the
 // wait for it and the workgroup barrier before any other lane loads (the consumer recipe of
 // MI355X_MICROARCH.md); the producer: every wave's stores drained by the workgroup barrier, an
-// agent-scope release by one lane, then the counter.  The polls are bounded (~seconds): a consumer that
+// agent-scope release by one lane, then the counter.  The polls are bounded (~30 s): a consumer that
 // gives up reports INT_MAX through `fail` -- a loud error, never a hang -- and chol_init checks on the
 // library's own streams that a polling kernel does not block its producer's stream (streams sharing a
 // hardware queue would) before the scheme is used at all.
@@ -211,7 +211,7 @@ __device__ __forceinline__ void sem_wait(const int *sem, int target, int *fail) 
   if (sem) {
     if (threadIdx.x == 0) {
       bool ok = false;
-      for (int i = 0; i < (1 << 21); ++i) {
+      for (int i = 0; i < (1 << 25); ++i) {  // ~30 s: a safety net only (chol_init has excluded the structural deadlock)
         if (__hip_atomic_load(sem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
           ok = true;
           break;
