@@ -201,7 +201,7 @@ int potrf_full_device(chol_desc *d, void *base) {
   T *M = reinterpret_cast<T *>(base);
   T *winv = reinterpret_cast<T *>(g.winv);
   const int nbm = mb / MACRO;
-  enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_PER_WAVE };
+  enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_NEAR, E_PN0, E_PN1, E_PER_WAVE };
   enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
   int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm + 1);
   if (rc) return rc;
@@ -226,6 +226,18 @@ int potrf_full_device(chol_desc *d, void *base) {
   const bool trsm_fused_on = cholmi::g_trsm_fused_min > 0;
   static const double pipe_fac = getenv("CHOLMI_PIPE_FACTOR") ? atof(getenv("CHOLMI_PIPE_FACTOR")) : 0.7;
   int open_bracket = -1;                      // odd wave whose profiling bracket is still open
+  // Plain waves of a few rounds of workgroups: the columns beyond k+1 go out as TWO launches, the near
+  // columns [k+2, bnd) on s_u1 behind the column-(k+1) launch and the far ones [bnd, nt) on s_main.  With a
+  // boundary that stays put for several waves each half depends on its own predecessor only (far(k+1) is a
+  // subset of far(k), near(k+1) of near(k)), so the last, partly filled round of one launch runs beside full
+  // rounds of the other chain's next launch instead of beside nothing; and column k+1 -- the next panel --
+  // waits for near(k-1) only.  The boundary moves (then near(k) also waits for far(k-1)) when the near part
+  // has shrunk under 30 % of the wave.
+  static const double halves_max_rounds =
+      getenv("CHOLMI_HALVES_MAX_ROUNDS") ? atof(getenv("CHOLMI_HALVES_MAX_ROUNDS")) : 24.0;
+  int bnd = -1;
+  bool prev_halves = false;
+  std::vector<int> halves_waves;
   HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
   if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
   // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): 3 nbm + 1
@@ -424,8 +436,31 @@ int potrf_full_device(chol_desc *d, void *base) {
       HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
       cols_pending = false;
     }
+    // halves: see above
+    const int tiles2 = r2.na + r2.nb;
+    bool halves = halves_max_rounds > 0 && concurrent && !pipe && !syrk_instream && split && nt - 1 - k >= 6 &&
+                  (double)tiles2 * nbm * nbm / 512.0 < halves_max_rounds;
+    bool moved = false;
+    if (halves) {
+      auto tiles_in = [&](int jlo, int jhi) {
+        const ColRange r = col_range(d, jlo, jhi);
+        return r.na + r.nb;
+      };
+      if (!prev_halves || bnd <= k + 2 || tiles_in(k + 2, bnd) * 10 < tiles2 * 3) {
+        int b = k + 3;
+        while (b < nt - 1 && tiles_in(k + 2, b) * 2 < tiles2) ++b;
+        // (the boundary only ever moves right, far(k) stays a subset of far(k-1); should it not, far(k) waits
+        // for near(k-1) as well)
+        if (prev_halves && b < bnd) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k - 1, E_NEAR), 0));
+        bnd = b;
+        moved = true;
+      }
+      if (bnd >= nt) halves = false;
+    }
+    if (prev_halves && !halves) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k - 1, E_NEAR), 0));  // U2(k) covers near(k-1)'s columns
     if (concurrent) {
-      if (k > 0) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));  // column k+1 was in U2(k-1)'s range
+      // column k+1 was in U2(k-1)'s range -- or in near(k-1)'s, which precedes this on s_u1
+      if (k > 0 && !prev_halves) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));
       HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
     } else if (g.profiling) {
       HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
@@ -446,9 +481,18 @@ int potrf_full_device(chol_desc *d, void *base) {
         HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
       }
       HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
+      if (halves && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_PN0), su));
       launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
       if (r1.na > 0) ++timed;
       HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
+      if (halves) {
+        const ColRange rn = col_range(d, k + 2, bnd);
+        if (moved && prev_halves) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));  // columns taken over from far(k-1)
+        launch_trail_update<T>(su, C, d->d_list, rn.off, rn.na, rn.offb, rn.nb, pan, yield);
+        ++timed;
+        HIPCHECK(hipEventRecord(ev(k, E_NEAR), su));
+        if (g.profiling) HIPCHECK(hipEventRecord(ev(k, E_PN1), su));
+      }
     } else {
       // the update dwarfs the panel: one launch for the whole column (one tail less per wave)
       launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
@@ -458,17 +502,25 @@ int potrf_full_device(chol_desc *d, void *base) {
     }
     if (!syrk_instream && !by_flags) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
     if (concurrent && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
-    if (r2.na + r2.nb > 0) {
+    if (halves) {
+      const ColRange rf = col_range(d, bnd, nt);
+      launch_trail_update<T>(g.s_main, C, d->d_list, rf.off, rf.na, rf.offb, rf.nb, pan, yield);
+      ++timed;
+      halves_waves.push_back(k);
+    } else if (r2.na + r2.nb > 0) {
       launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
       ++timed;
     }
     HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
     if (g.profiling) {
       // the bracket [P0, P1] on s_main covers every k_trail_update launch of the wave: U1(k) started
-      // with U2(k); waiting for its end here constrains nothing (U2(k+1) needs panel k+1, which needs it)
-      if (concurrent) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
+      // with U2(k); waiting for its end here constrains nothing (U2(k+1) needs panel k+1, which needs it).
+      // (halves: far(k+1) does NOT need near(k) -- two brackets, [PN0, PN1] on s_u1 for column k+1 and the
+      // near half, and the host takes the union)
+      if (concurrent && !halves) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
       HIPCHECK(hipEventRecord(ev(k, E_P1), g.s_main));
     }
+    prev_halves = halves;
     upd_launches += timed;
     // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
     // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
@@ -494,10 +546,25 @@ int potrf_full_device(chol_desc *d, void *base) {
   g.update_launches = upd_launches;
   g.update_ms = 0;
   if (g.profiling) {
-    for (int k = 0; k + 1 < nt; ++k) {
-      float a = 0;
-      HIPCHECK(hipEventElapsedTime(&a, ev(k, E_P0), ev(k, E_P1)));
-      g.update_ms += a;
+    // union of the brackets (disjoint by construction except around the waves launched as halves)
+    std::vector<std::pair<float, float>> iv;
+    auto add = [&](hipEvent_t a, hipEvent_t b) -> int {
+      float t0 = 0, t1 = 0;
+      HIPCHECK(hipEventElapsedTime(&t0, fixed[F_START], a));
+      HIPCHECK(hipEventElapsedTime(&t1, fixed[F_START], b));
+      if (t1 > t0) iv.emplace_back(t0, t1);
+      return 0;
+    };
+    for (int k = 0; k + 1 < nt; ++k)
+      if ((rc = add(ev(k, E_P0), ev(k, E_P1)))) return rc;
+    for (int k : halves_waves)
+      if ((rc = add(ev(k, E_PN0), ev(k, E_PN1)))) return rc;
+    std::sort(iv.begin(), iv.end());
+    float hi = -1;
+    for (auto &p : iv) {
+      if (p.first > hi) g.update_ms += p.second - p.first;
+      else if (p.second > hi) g.update_ms += p.second - hi;
+      hi = std::max(hi, p.second);
     }
   }
   int info = 0;
