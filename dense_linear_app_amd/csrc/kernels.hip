@@ -1309,6 +1309,118 @@ __global__ __launch_bounds__(256, 2) void k_small_update(T *C, long ldc, const T
   sem_signal(signal_sem);  // (one count per workgroup that has a block: n (n + 1) / 2 of the n x n grid when !full)
 }
 
+// One in-tile POTRF step in ONE launch (chain-bound form, section "device-side dependencies"): the first
+// 4 nr workgroups are k_solve_small's (X = A Winv_s^T for the 32-row slabs of block rows s+1.. of block column
+// s, in place) and count up `cnt`; the others are k_small_update's for the n (n + 1) / 2 lower 64 x 64 blocks
+// of the trailing part (n = 2 nr): resident from the start with their block of C loaded, they poll `cnt` for
+// the 4 nr solves and apply C -= X X^T.  Workgroups are dispatched in index order, so the solves never wait
+// behind the pollers.  Saves the second launch of the step (drain, dispatch, cold loads) on the critical chain.
+template <typename T>
+struct IntileLds {
+  union {
+    struct {
+      SmallImg<T, 32> a;
+      SmallImg<T, MACRO> b;
+    } sv;
+    struct {
+      SmallImg<T, 64> a, b;
+    } up;
+  };
+};
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_intile_step(T *tile, int mb, int nbm, int s, const T *__restrict__ winv,
+                                                        int *ytab, int *cnt, int *fail) {
+  __shared__ IntileLds<T> L;
+  const int nr = nbm - 1 - s, nsolve = 4 * nr;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15;
+  typename Tr<T>::acc_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+  if ((int)blockIdx.x < nsolve) {
+    GuestOnCu guest(ytab);
+    __builtin_amdgcn_s_setprio(2);
+    T *Ap = tile + (long)(s + 1) * MACRO + 32 * (int)blockIdx.x + (long)s * MACRO * mb;
+    const T *Bp = winv + (long)s * MACRO * MACRO;
+    T ra[32 * SK / 256], rb[MACRO * SK / 256];
+    small_gload<T, 32>(Ap, mb, 0, ra);
+    small_gload<T, MACRO>(Bp, MACRO, 0, rb);
+    for (int ph = 0; ph < MACRO / SK; ++ph) {
+      small_lstore<T, 32>(L.sv.a, ra);
+      small_lstore<T, MACRO>(L.sv.b, rb);
+      __syncthreads();
+      if (ph + 1 < MACRO / SK) {
+        small_gload<T, 32>(Ap, mb, (ph + 1) * SK, ra);
+        small_gload<T, MACRO>(Bp, MACRO, (ph + 1) * SK, rb);
+      }
+      small_mma<T, 32, MACRO>(L.sv.a, L.sv.b, 0, 32 * w, acc);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Ap[16 * a + lo + (long)(32 * w + 16 * b + Tr<T>::drow(lane, r)) * mb] = acc[a][b][r];
+    guest.leave();
+    sem_signal(cnt);
+    return;
+  }
+  // the idx-th lower block, column by column
+  int c64 = 0, left = (int)blockIdx.x - nsolve, len = 2 * nr;
+  while (left >= len) {
+    left -= len;
+    --len;
+    ++c64;
+  }
+  const int r64 = c64 + left;
+  T *tr = tile + (long)(s + 1) * MACRO * (mb + 1);                        // trailing part of the tile
+  const T *xs = tile + (long)(s + 1) * MACRO + (long)s * MACRO * mb;      // block column s below the diagonal
+  const T *Ap = xs + 64 * r64, *Bp = xs + 64 * c64;
+  T *Cp = tr + 64 * r64 + (long)64 * c64 * mb;
+  const int i0 = 32 * (w & 1), j0 = 32 * (w >> 1);
+  T cv[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cv[a][b][r] = Cp[(i0 + 16 * a + lo) + (long)(j0 + 16 * b + Tr<T>::drow(lane, r)) * mb];
+  sem_wait(cnt, nsolve, fail);
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
+  T ra[64 * SK / 256], rb[64 * SK / 256];
+  small_gload<T, 64>(Ap, mb, 0, ra);
+  small_gload<T, 64>(Bp, mb, 0, rb);
+  for (int ph = 0; ph < MACRO / SK; ++ph) {
+    small_lstore<T, 64>(L.up.a, ra);
+    small_lstore<T, 64>(L.up.b, rb);
+    __syncthreads();
+    if (ph + 1 < MACRO / SK) {
+      small_gload<T, 64>(Ap, mb, (ph + 1) * SK, ra);
+      small_gload<T, 64>(Bp, mb, (ph + 1) * SK, rb);
+    }
+    small_mma<T, 64, 64>(L.up.a, L.up.b, i0, j0, acc);
+    __syncthreads();
+  }
+  const bool dg = r64 == c64;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * a + lo, j = j0 + 16 * b + Tr<T>::drow(lane, r);
+        if (!dg || i >= j) Cp[i + (long)j * mb] = cv[a][b][r] - acc[a][b][r];
+      }
+  guest.leave();
+}
+
 // generic one-tile C := alpha*A*B^T + beta*C (GEMM NoTrans/Trans, or SYRK Lower)
 // blockIdx.z = z1 + nz1 * z2 selects the tiles of a batch: A + z1 sA, B + z2 sB, C + z1 sC1 + z2 sC2
 // (potrs: Z(r,i) -= Z(r,k) L(i,k)^T for all right-hand-side tile rows r and tile columns i in one launch)
@@ -2207,6 +2319,7 @@ unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_sta
 int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four waves + register staging, 2..5 eight waves (MODE = variant - 2: bit 0 DMA behind the first MFMAs, bit 1 static priority); fp32 always 0 / 1 (CHOLMI_VARIANT)
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
+int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
 int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
 int g_late_dma = 0;  // four-wave update (fp32; fp64 with CHOLMI_VARIANT=0): DMA behind the first MFMAs -- fp64 +0.9 %, fp32 -6.6 % (twice the MFMA rate: the burst is better out of the way early); CHOLMI_LATE_DMA
@@ -2377,13 +2490,21 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                        wait_target, pipe ? slot(s) : nullptr);
     if (nr > 0) {
       if (g_intile_small) {
-        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
-                                                 pipe ? slot(nbm + s) : nullptr);
-        T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
-        const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
-        // (launching this one ahead of time too -- on st, polling the in-tile solve's counter, the next
-        // diagonal-block step polling its own -- measured -1 ... -5 %: it queues behind the previous TRSM step)
-        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
+        if (pipe && g_intile_fused) {
+          // solve and update of the step in one launch, the update's workgroups polling the solves' counter
+          // (which the TRSM step's update on st polls too)
+          k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab, slot(nbm + s),
+                                                                       d_info);
+        } else {
+          k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
+                                                   pipe ? slot(nbm + s) : nullptr);
+          T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
+          const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
+          // (launching the update ahead of time on another stream, polling the in-tile solve's counter, the
+          // next diagonal-block step polling its own: -1 ... -5 % on st, -10 ... -20 % on su -- it queues
+          // behind that stream's own launches)
+          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
+        }
       } else {
         k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
         k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
