@@ -1474,14 +1474,19 @@ __device__ __forceinline__ float rlane(float v, int lane) {
 
 // acc(D layout) += First(16x16) * Second(16x16); element (i,k) of First at F[i*fi + k*fk],
 // element (k,j) of Second at Sd[k*sk + j*sj].  Lane l ends up with D[drow(l,reg)][l & 15].
+// swz = 1 / 2: First / Second is a 16x16 block stored column-major, ld 16, with the rows of column c rotated
+// by c (wd_idx): the layout of the diagonal blocks' inverses, which are written and read a column per lane
+// (unrotated, all sixteen lanes of such an access fall on one LDS bank; a leading dimension of 17 would
+// cost the kilobyte that lets the kernel share a CU with a trailing-update workgroup)
+__device__ __forceinline__ int wd_idx(int r, int c) { return ((r + c) & 15) + 16 * c; }
 template <typename T>
 __device__ __forceinline__ void mm16(typename Tr<T>::acc_t &acc, const T *F, int fi, int fk,
-                                     const T *Sd, int sk, int sj, bool negate) {
+                                     const T *Sd, int sk, int sj, bool negate, int swz = 0) {
   const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    T f = F[lo * fi + (4 * q + hi) * fk];
-    const T g = Sd[(4 * q + hi) * sk + lo * sj];
+    T f = (swz == 1) ? F[wd_idx(lo, 4 * q + hi)] : F[lo * fi + (4 * q + hi) * fk];
+    const T g = (swz == 2) ? Sd[wd_idx(4 * q + hi, lo)] : Sd[(4 * q + hi) * sk + lo * sj];
     if (negate) f = -f;
     acc = Tr<T>::mfma(f, g, acc);
   }
@@ -1551,7 +1556,7 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
       for (int bb = 0; bb < H - t; ++bb) {
         const int b = g0 + bb, c = b + t;
         const T *Sec = (t == 0) ? Wd[c] : S + db_off(c, b);
-        mm16<T>(acc[bb], S + db_off(a, c), 1, DB_LD, Sec, 1, (t == 0) ? 16 : DB_LD, false);
+        mm16<T>(acc[bb], S + db_off(a, c), 1, DB_LD, Sec, 1, DB_LD, false, (t == 0) ? 2 : 0);
       }
 #pragma unroll
     for (int bb = 0; bb < H; ++bb) {
@@ -1573,7 +1578,7 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
       for (int aa = t; aa < H; ++aa) {  // (product aa has terms c = g0 + H .. a, i.e. t = 0 .. aa)
         const int a = g0 + H + aa, c = g0 + H + t;
         const T *Fp = (t == aa) ? Wd[a] : S + db_off(a, c);
-        mm16<T>(acc[aa], Fp, 1, (t == aa) ? 16 : DB_LD, S + db_off(c, b), 1, DB_LD, true);
+        mm16<T>(acc[aa], Fp, 1, DB_LD, S + db_off(c, b), 1, DB_LD, true, (t == aa) ? 1 : 0);
       }
 #pragma unroll
     for (int aa = 0; aa < H; ++aa) {
@@ -1829,11 +1834,27 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #define DEFER(k)                                                     \
   do {                                                               \
     constexpr int c_ = jj + 1 + (k);                                 \
-    if constexpr (jj >= 1 && c_ < NB) dd[c_] -= dd[jj - 1] * prev.at(c_); \
+    if constexpr (jj >= 1 && c_ < NB && !(sizeof(T) == 8 && (k) == 0)) dd[c_] -= dd[jj - 1] * prev.at(c_); \
   } while (0)
+          // fp64: the pivot chain proper is  d -> v_rsq -> g, e, (g, h), e, h  and then STRAIGHT to the next
+          // pivot:  d' = x - u^2,  u = (2a) h = a / sqrt(d)  (h = 1 / (2 sqrt(d)); x = A(jj+1,jj+1) and
+          // a = A(jj+1,jj) before the scaling, both in lane jj+1) -- the square root, the scaled column, its
+          // selects and the rank-1 update of column jj+1 (whose lane jj+1 nobody reads any more) are off the
+          // chain, and the next column's v_rsq is already in flight while they issue.  u is the very value
+          // the scaled column holds in that lane (2h is exact), so the factor is bit for bit what the
+          // straightforward order gives.
+          double dcur = 0, rcur = 0;
+          T a2n = T(0);  // 2 a, a = the unscaled column about to be eliminated
+          if constexpr (sizeof(T) == 8) {
+            dcur = rlane(dd[0], 0);
+            rcur = __builtin_amdgcn_rsq(dcur);
+            a2n = dd[0] + dd[0];
+          }
           static_for<0, NB>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
-            const T d = rlane(dd[jj], jj);
+            T d;
+            if constexpr (sizeof(T) == 8) d = (T)dcur;
+            else d = rlane(dd[jj], jj);
             if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
             T sq, rinv;
             if constexpr (sizeof(T) == 8) {
@@ -1846,32 +1867,40 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
     constexpr int a_ = jj + 1 + (k0), b_ = jj + 1 + (k1);                                                \
     if constexpr (jj >= 1 && b_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]), "+v"(dd[b_]));           \
     else if constexpr (jj >= 1 && a_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]));                    \
+    else asm volatile("" : "+v"(x));                                                                     \
   } while (0)
-              double r = __builtin_amdgcn_rsq((double)d);
-              double g = d * r, h = 0.5 * r;
+              const double r = rcur;
+              // +Inf passes `d > 0` in LAPACK too (dpotf2: sqrt(Inf) = Inf, the column is scaled by 1/Inf = 0,
+              // info stays 0).  v_rsq(Inf) = 0; with the product d r taken on min(d, DBL_MAX) the iteration
+              // stays at g = h = 0 (instead of Inf * 0 = NaN), so 1/pivot = 0 and the next pivot is left
+              // alone, as there; only sqrt(d) itself needs the select below
+              const double dm = __builtin_fmin((double)d, 1.7976931348623157e308);
+              double g = dm * r, h = 0.5 * r;
               double e = __builtin_fma(-h, g, 0.5);
-              if constexpr (jj >= 1) prev.wait(e);
-              DEFER(0); DEFER(1); PIN2(e, 0, 1);
               g = __builtin_fma(g, e, g);
               h = __builtin_fma(h, e, h);
-              DEFER(2); DEFER(3); PIN2(h, 2, 3);
               e = __builtin_fma(-h, g, 0.5);
-              DEFER(4); DEFER(5); PIN2(e, 4, 5);
-              g = __builtin_fma(g, e, g);
               h = __builtin_fma(h, e, h);
-              DEFER(6); DEFER(7); PIN2(h, 6, 7);
+              // (column jj-1's update of column jj+1 was applied from the lane at the end of the last
+              // iteration: the burst of LDS reads behind column jj-1, issued just ahead of this chain, is
+              // not on the way to the next pivot)
+              if constexpr (jj + 1 < NB) {
+                const double u = (double)a2n * h;  // = a (2h) = a / sqrt(d), rounded as the scaled column is
+                const double tn = __builtin_fma(-u, u, (double)dd[jj + 1]);
+                dcur = rlane(tn, jj + 1);
+                rcur = __builtin_amdgcn_rsq(dcur);
+                PIN2(rcur, 1, 2);  // the next column's v_rsq issues here, ahead of everything below
+              }
+              g = __builtin_fma(g, e, g);
+              if constexpr (jj >= 1) prev.wait(g);
+              DEFER(1); DEFER(2); DEFER(3); PIN2(g, 1, 2);
               const double cc = __builtin_fma(-g, g, (double)d);
               rinv = (T)(h + h);
-              DEFER(8); DEFER(9); PIN2(rinv, 8, 9);
+              DEFER(4); DEFER(5); DEFER(6); PIN2(rinv, 4, 5);
               sq = (T)__builtin_fma(cc, h, g);
-              DEFER(10); DEFER(11); DEFER(12); DEFER(13);
-              // +Inf passes `d > 0` in LAPACK too (dpotf2: sqrt(Inf) = Inf, the column is scaled by
-              // 1/Inf = 0, info stays 0); v_rsq(Inf) = 0 would turn it into NaN here.  d is
-              // wave-uniform (SGPRs): a scalar compare and two selects
-              if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0) {
+              DEFER(7); DEFER(8); DEFER(9); DEFER(10); DEFER(11); DEFER(12); DEFER(13);
+              if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0)
                 sq = (T)__builtin_huge_val();
-                rinv = T(0);
-              }
 #undef PIN2
             } else {
               if constexpr (jj >= 1) prev.wait();
@@ -1889,8 +1918,15 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
             if constexpr (jj + 2 < NB) prev.issue((unsigned)(size_t)Lc + jj * NB * (unsigned)sizeof(T), dd[jj]);
-            // the next pivot's column: L(jj+1, jj) straight from the lane (critical chain)
-            if constexpr (jj + 1 < NB) dd[jj + 1] -= dd[jj] * rlane(dd[jj], jj + 1);
+            // column jj+1 by column jj, L(jj+1, jj) straight from the lane (fp32: this is the way to the next
+            // pivot; fp64: the rows below it only)
+            if constexpr (jj + 1 < NB) {
+              dd[jj + 1] -= dd[jj] * rlane(dd[jj], jj + 1);
+              if constexpr (sizeof(T) == 8 && jj + 2 < NB) {
+                a2n = dd[jj + 1] + dd[jj + 1];
+                dd[jj + 2] -= dd[jj] * rlane(dd[jj], jj + 2);  // (what DEFER(0) of the next iteration would do, early)
+              }
+            }
           });
 #undef DEFER
           if (bad) {
@@ -1933,7 +1969,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
               }
             } else if (lane_ < NB) {
 #pragma unroll
-              for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane_ * NB] = a[jj];
+              for (int jj = 0; jj < NB; ++jj) Wd[p][wd_idx(jj, lane_)] = a[jj];
             }
           }
         }
@@ -2029,7 +2065,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       }
       if (lane < NB) {
 #pragma unroll
-        for (int jj = 0; jj < NB; ++jj) Wd[p][jj + lane * NB] = x[jj];
+        for (int jj = 0; jj < NB; ++jj) Wd[p][wd_idx(jj, lane)] = x[jj];
       }
     }
   }
@@ -2050,10 +2086,10 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = T(0);
     if (gr == c) {
-      const T *src = Wd[c] + (gi & 15);
+      const T *src = Wd[c];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if ((gi & 15) >= u) v[u] = src[u * NB];
+        if ((gi & 15) >= u) v[u] = src[wd_idx(gi & 15, u)];
     } else if (gr > c) {
       const T *src = S + db_off(gr, c) + (gi & 15);
 #pragma unroll
