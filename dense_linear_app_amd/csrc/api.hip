@@ -194,6 +194,11 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
 //                   blocks go first and U2's fill whatever U1 -- at most one round of workgroups
 //                   on a mid-size matrix -- leaves idle
 // U1(k) waits for U2(k-1), whose range includes column k+1; U2(k) follows U2(k-1) in stream order.
+// Three regimes by the length of a wave's update against its panel chain: panels in pairs (two per pass of
+// the far columns) while it is more than two chains long; the columns beyond k+1 as a near and a far launch
+// on s_u1 / s_main in the mid waves; and, once it is shorter than the chain, the counter-linked form -- TRSM
+// steps, SYRK slices and the next POTRF launched ahead of time and polling device-side counters, no stream
+// event on the chain (cholmi_internal.h: SyrkPipe; kernels.hip: sem_wait).
 template <typename T>
 int potrf_full_device(chol_desc *d, void *base) {
   const int nt = d->nt, mb = d->mbi;

@@ -2502,6 +2502,10 @@ void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
 // for -- still follows the POTRF step by step.  ev_head (may be null) is recorded on `st` when the
 // head tile is done.
 // ev: nbm events.  Both streams must be joined by the caller.
+// sy != null: the counter-linked form of a chain-bound wave (SyrkPipe) -- the same launches, plus the SYRK
+// on the next diagonal tile in K = 128 slices on sy->su, every dependency between the streams a polled
+// counter instead of an event; wait_sem / wait_target: what the first diagonal-block step polls (the
+// previous wave's last slice), or null.
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
