@@ -2391,18 +2391,7 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
   }
   if (g_variant >= 2 && sizeof(T) == 8) {
     if constexpr (sizeof(T) == 8) {
-      // EXPERIMENT (CHOLMI_YIELD_DYNLDS): in yielding waves ask for so much extra LDS that only ONE update
-      // workgroup fits on a CU, so that the panel chain's kernels find room on every CU at once
-      static const int dyn_env = getenv("CHOLMI_YIELD_DYNLDS") ? atoi(getenv("CHOLMI_YIELD_DYNLDS")) : 0;
-      static const double dyn_fac = getenv("CHOLMI_YIELD_DYNLDS_FACTOR") ? atof(getenv("CHOLMI_YIELD_DYNLDS_FACTOR")) : 1e9;
-      const double upd_est = (double)(tot_a + tot_b) / MT * 2.0 * C.mb * (double)C.mb * C.mb / 65e12 * npan;
-      const int dyn = (yield && dyn_env > 0 && upd_est < dyn_fac * nbm * 195e-6) ? dyn_env : 0;
-      static bool attr_set = false;
-      if (dyn && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_trail_update_w8<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_env);
-        attr_set = true;
-      }
-#define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), dyn, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
+#define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
                                                      yield ? g_ytab : nullptr, p2, npan)
       switch (g_variant - 2) {
         case 1: W8(1); break;
