@@ -2356,7 +2356,7 @@ int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four wave
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
-int g_trsm_small_max = 32;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
+int g_trsm_small_max = 64;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
 int g_late_dma = 0;  // four-wave update (fp32; fp64 with CHOLMI_VARIANT=0): DMA behind the first MFMAs -- fp64 +0.9 %, fp32 -6.6 % (twice the MFMA rate: the burst is better out of the way early); CHOLMI_LATE_DMA
 int g_f32_w8 = 1;  // fp32 trailing update on eight waves with K-slices of 32 (CHOLMI_F32_W8=0: the four-wave kernel)
