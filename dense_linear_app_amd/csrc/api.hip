@@ -796,6 +796,7 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
+  if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
   if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);

@@ -220,7 +220,7 @@ __device__ __forceinline__ void sem_wait(const int *sem, int target, int *fail) 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!ok && fail) atomicExch(fail, 0x7fffffff);
+      if (!ok && fail) atomicExch(fail, 0x7ffffffe);  // (INT_MAX - 1: told apart from the diagonal-block kernel's INT_MAX)
     }
     __syncthreads();
   }
@@ -249,6 +249,22 @@ __global__ void k_sem_probe_wait(const int *sem, int *result) {
   *result = ok;
 }
 __global__ void k_sem_probe_set(int *sem) { sem_signal(sem); }
+
+// A stream's dependency on a counter, as a launch of its own: ONE wave polls, the kernel behind it in the
+// stream starts when it ends.  Grids of more than a few dozen workgroups never poll themselves: resident
+// pollers hold LDS and registers, and enough of them can keep the very kernel they wait for (an in-tile
+// solve, a diagonal block) from finding a CU -- a deadlock until the poll's bound, seen with two processes
+// time-sliced on one GPU.  The pollers that remain are single workgroups (the next POTRF's first step) or
+// sit behind their producers in the same launch (k_intile_step).
+__global__ void k_sem_gate(const int *sem, int target, int *fail) { sem_wait(sem, target, fail); }
+extern int g_poll_max_wgs;
+// true: the kernel about to be launched (of `wgs` workgroups) may poll `sem` itself; false: a gate was launched
+inline bool poll_in_kernel(hipStream_t s, const int *sem, int target, int *fail, long wgs) {
+  if (!sem) return false;
+  if (wgs <= g_poll_max_wgs) return true;
+  k_sem_gate<<<1, 64, 0, s>>>(sem, target, fail);
+  return false;
+}
 
 // ------------------------------------------------------------------------------
 // "Paired" form of the NT core (trailing update): fragment rows are interleaved so that
@@ -1658,7 +1674,8 @@ struct ColBurst<float> {
 // and written last, so a satisfied counter vouches for the data behind it).  One opaque instruction
 // sequence on purpose: written as a C loop, sixteen unrolled copies of it gave the register allocator
 // a control-flow graph on which the kernel needed 400 VGPRs instead of 256.  Bounded (the producer
-// needs ~1 us per column even beside a running update; the bound is ~1 ms): on giving up it stores
+// needs ~1 us per column even beside a running update; the bound is ~0.5 s of polling -- two processes
+// time-sliced on one GPU were seen to exceed a 1 ms bound): on giving up it stores
 // a value other than 0 / 1 into DiagLds::failed, which the kernel turns into info = INT_MAX after
 // the panel's barrier -- a logic error shows up as a loud failure, never as a hung GPU or a
 // silently wrong factor.  (Returning a flag instead and testing it in C++ put the kernel back over
@@ -1673,7 +1690,7 @@ struct ColFetch<double> {
   __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
   __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
                                         unsigned failed_addr) {
-    int v, n = 0x3fff;
+    int v, n = 0x3fffff;
     asm volatile(
         "1:\n\t"
         "ds_read_b32 %0, %11\n\t"
@@ -1711,7 +1728,7 @@ struct ColFetch<float> {
   __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
   __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
                                         unsigned failed_addr) {
-    int v, n = 0x3fff;
+    int v, n = 0x3fffff;
     asm volatile(
         "1:\n\t"
         "ds_read_b32 %0, %11\n\t"
@@ -2356,6 +2373,7 @@ int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four wave
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
+int g_poll_max_wgs = 48;  // grids up to this many workgroups poll their counter themselves, larger ones behind a gate (CHOLMI_POLL_MAX_WGS)
 int g_trsm_small_max = 64;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
 int g_late_dma = 0;  // four-wave update (fp32; fp64 with CHOLMI_VARIANT=0): DMA behind the first MFMAs -- fp64 +0.9 %, fp32 -6.6 % (twice the MFMA rate: the burst is better out of the way early); CHOLMI_LATE_DMA
@@ -2431,22 +2449,28 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
               T alpha, const StepSems &sm = StepSems()) {
   const int nbm = mb / MACRO, nc = nbm - 1 - st;
   if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
-    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab, sm.diag, 1,
-                                                      sm.fail, sm.head);
-    if (nc > 0)
+    const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm * 4);
+    k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab,
+                                                      p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
+    if (nc > 0) {
+      const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, 4L * nbm * nc * ntiles);
       k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
           tiles + (long)(st + 1) * MACRO * mb, mb, tiles + (long)st * MACRO * mb,
-          lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz, nullptr, sm.intile,
-          sm.intile_target, sm.fail);
+          lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz, nullptr,
+          p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
+    }
     return 4 * nbm;
   }
   // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
   // first update of blocks > 0
+  const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm);
   k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab,
-                                                sm.diag, 1, sm.fail, sm.head);
-  if (nc > 0)
+                                                p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
+  if (nc > 0) {
+    const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, (long)ntiles * nbm * nc);
     k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab,
-                                                        sm.intile, sm.intile_target, sm.fail);
+                                                        p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
+  }
   return nbm;
 }
 
@@ -2562,9 +2586,11 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.fail = d_info;
       const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
       const T *xs = tiles + (long)s * MACRO * mb;
+      const long nslice = (long)(mb / 64) * (mb / 64 + 1) / 2;
+      const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice);
       k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, sy->su>>>(
           reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0, s == nbm - 1 ? slot(3 * nbm) : nullptr,
-          slot(2 * nbm + s), head_wgs, d_info);
+          ps ? slot(2 * nbm + s) : nullptr, head_wgs, d_info);
       continue;
     }
     // (recorded behind the in-tile update, not between the solve and the update: an event record

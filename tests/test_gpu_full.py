@@ -345,3 +345,32 @@ def test_walker_schedule_variants_match_the_oracle(env, orc):
     Lref = np.tril(orc.tile_to_lapack(T, N, B))
     assert np.abs(np.tril(Ld) - Lref).max() / np.abs(Lref).max() <= 1e-12
     assert np.abs(np.tril(Ls).astype(np.float64) - Lref).max() / np.abs(Lref).max() <= 1e-4
+
+
+def test_two_processes_factorising_on_one_gpu_do_not_starve_each_other():
+    """The counter-linked form of a chain-bound wave launches consumer kernels ahead of time and lets them poll.
+    Large polling grids once held so much LDS that the kernel they waited for found no CU -- a deadlock until the
+    poll's bound (info = INT_MAX - 1), seen with two processes time-sliced on one GPU at exactly this shape.
+    Grids above a few dozen workgroups now wait behind a one-wave gate kernel instead (kernels.hip: k_sem_gate)."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from dense_linear_app_amd import chameleon as ch\n"
+        "ch.CHAMELEON_Init(1, 1)\n"
+        "for N, B, reps in ((8192, 1024, 12), (4096, 512, 30)):\n"
+        "    d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, 1, 1)\n"
+        "    for r in range(reps):\n"
+        "        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 7 + r)\n"
+        "        info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)\n"
+        "        res = ch.residual_plgsy(d, float(N), 7 + r)\n"
+        "        assert info == 0 and res <= 1e-13, (N, B, r, info, res)\n"
+        "print('ok')\n"
+    ) % root
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in out, (out, err[-2000:])
