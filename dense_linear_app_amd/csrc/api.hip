@@ -796,6 +796,14 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
+  {
+    // grids that may poll a counter themselves: few enough that, one per CU in the worst case, most CUs
+    // stay free of pollers (kernels.hip: k_sem_gate); on a small partition every grid waits behind a gate
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, g.device));
+    const int room = (prop.multiProcessorCount - 32) / 4;
+    cholmi::g_poll_max_wgs = room < 0 ? 0 : (room < 48 ? room : 48);
+  }
   if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
