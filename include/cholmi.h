@@ -98,7 +98,10 @@ int chol_desc_destroy(chol_desc_t **desc);
  * DAG of C2:506-565 runs on the device) and on a p x q block-cyclic descriptor (one process per GPU,
  * ChamLower; needs a transport, see chol_set_transport below).  ChamUpper is served for device-resident
  * matrices by transposing the storage in place around the Lower factorisation (the strict
- * lower triangle is returned untouched). */
+ * lower triangle is returned untouched).
+ * Returns LAPACK's info (0, or the 1-based index of the first non-positive pivot), a negative CHOL_ERR_*,
+ * or -- never expected -- INT_MAX / INT_MAX - 1: a bounded device-side wait inside the library gave up
+ * (the factor is then invalid). */
 int chol_potrf_tile(int uplo, chol_desc_t *A);
 
 /* CHAMELEON_dtrsm_Tile(side, uplo, trans, diag, alpha, A, B) W2:323.
