@@ -313,7 +313,9 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
                                  {"CHOLMI_PIPE_FACTOR": "0.02"},
                                  # near / far halves of the update on two streams, boundary moving every few waves
                                  {"CHOLMI_PIPE_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
-                                 {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"}])
+                                 {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"},
+                                 # counters: every grid behind a gate kernel / every grid polling itself
+                                 {"CHOLMI_POLL_MAX_WGS": "0"}, {"CHOLMI_POLL_MAX_WGS": "100000"}])
 def test_walker_schedule_variants_match_the_oracle(env, orc):
     """The walker picks its schedule by size (two panels per pass only while a wave's update is long, and so
     on), so at oracle-sized problems the default run never enters some of them.  Each variant forced through
