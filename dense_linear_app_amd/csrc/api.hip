@@ -25,7 +25,8 @@ extern "C" void chol_internal_dist_finalize(void);
 namespace {
 
 constexpr int SEM_SLOTS = 16384;          // device-side counters: 3 mb/128 + 1 per tile column ...
-constexpr int SEM_INTS = SEM_SLOTS * 32;  // ... each on a 128-byte line of its own
+constexpr int TILE_SEM_SETS = 8;          // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
+constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
 
 struct Ctx {
   bool inited = false;
@@ -37,6 +38,7 @@ struct Ctx {
   int *d_info = nullptr;
   int *d_ytab = nullptr;  // per-CU yield requests (kernels.hip: cooperative CU hand-over)
   int *d_sem = nullptr;   // device-side dependency counters of the panel chain (kernels.hip: sem_wait), or null
+  unsigned tile_sem_next = 0;
   double *d_acc = nullptr;
   void *stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_bytes[3] = {0, 0, 0};
@@ -68,6 +70,12 @@ int fail(int code, const char *msg) {
 }
 
 inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// counters for one single-tile POTRF (launch_potrf_tile): a set of 32, rotating so that consecutive
+// factorisations on different streams never share one
+int *tile_sems() {
+  return g.d_sem ? g.d_sem + (size_t)(SEM_SLOTS + 32 * (g.tile_sem_next++ % TILE_SEM_SETS)) * 32 : nullptr;
+}
 
 int ensure_stage(int idx, size_t bytes) {
   if (g.stage_bytes[idx] >= bytes) return 0;
@@ -618,7 +626,7 @@ static int potrf_impl(chol_desc *A, bool upper_staged = false) {
     // back exactly as it went in
     if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
     launch_potrf_tile<T>(g.s_main, reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.winv),
-                         g.d_info, 0);
+                         g.d_info, 0, tile_sems());
     if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
     rc = stage_out<T>(A, st);
     if (rc) return rc;
@@ -1482,9 +1490,9 @@ int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
   CHECK_WINV(d, "wave_potrf");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_potrf_tile<double>(s, (double *)lkk, d->mbi, (double *)g.winv, g.d_info, k * d->mbi);
+    launch_potrf_tile<double>(s, (double *)lkk, d->mbi, (double *)g.winv, g.d_info, k * d->mbi, tile_sems());
   else
-    launch_potrf_tile<float>(s, (float *)lkk, d->mbi, (float *)g.winv, g.d_info, k * d->mbi);
+    launch_potrf_tile<float>(s, (float *)lkk, d->mbi, (float *)g.winv, g.d_info, k * d->mbi, tile_sems());
   HIPCHECK(hipGetLastError());
   return 0;
 }

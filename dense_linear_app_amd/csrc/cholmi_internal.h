@@ -82,7 +82,7 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
 // MACRO*MACRO elements, ld = MACRO).  info: device int, set to info_base + j (1-based)
 // at the first non-positive pivot (first writer wins).
 template <typename T>
-void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base);
+void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base, int *sem = nullptr);
 
 // C (mb x mb tile, lower part) -= A A^T, A one tile: 64 x 64 blocks, one workgroup each (critical chain)
 template <typename T>

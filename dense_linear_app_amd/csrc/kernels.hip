@@ -2480,16 +2480,21 @@ void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb) {
   k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, s>>>(C, mb, A, A, mb, mb, g_ytab, 0, 0, 0);
 }
 
+// sem (may be null): mb / 128 counters, 32 ints apart, for the fused in-tile steps (k_intile_step); zeroed here
 template <typename T>
-void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base) {
+void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base, int *sem) {
   const int nbm = mb / MACRO;
+  const bool fused_steps = sem && g_intile_small && g_intile_fused && nbm > 1;
+  if (fused_steps) (void)hipMemsetAsync(sem, 0, (size_t)nbm * 32 * sizeof(int), s);
   for (int st = 0; st < nbm; ++st) {
     k_potrf_diag<T><<<1, 256, 0, s>>>(tile + (long)st * MACRO * (mb + 1), mb,
                                       winv + (long)st * MACRO * MACRO, d_info, info_base + st * MACRO, 1, g_dbg, g_ytab);
     const int nr = nbm - 1 - st;
     if (nr > 0) {
       // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
-      if (g_intile_small) {
+      if (fused_steps) {
+        k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, s>>>(tile, mb, nbm, st, winv, g_ytab, sem + 32 * st, d_info);
+      } else if (g_intile_small) {
         k_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, 0, mb, nbm, st + 1, st, winv, T(1), g_ytab);
         {
           T *tr = tile + (long)(st + 1) * MACRO * (mb + 1);  // trailing part of the tile
@@ -2719,7 +2724,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int, int,  \
                                        int, const PanelRef &, bool, const PanelRef *);              \
-  template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int);                       \
+  template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int, int *);                \
   template void launch_diag_syrk<T>(hipStream_t, T *, const T *, int);                               \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \
   template void launch_trsm_panel<T>(hipStream_t, T *, long, int, const T *, const T *, int, T);    \
