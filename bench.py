@@ -37,14 +37,17 @@ def parse():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-N", type=int, default=20480)  # ~3 s of oracle + ~4 s of vendor LAPACK on 16 cores, plus generation
+    # the CPU baseline is quoted at N=16384, tile=512 (config 2's shape): ~1.5 s of oracle +
+    # ~2 s of vendor LAPACK on 16 cores; --cpu-extra-N adds a second, larger sample to the line
+    ap.add_argument("--cpu-N", type=int, default=16384)
     ap.add_argument("--cpu-tile", type=int, default=512)
+    ap.add_argument("--cpu-extra-N", type=int, default=20480)
     ap.add_argument("--no-check", action="store_true",
                     help="skip the (untimed) residual of the last step's factor; by default it is in the line")
     return ap.parse_args()
 
 
-def cpu_baseline(N: int, B: int, seed: int) -> dict:
+def cpu_baseline(N: int, B: int, seed: int, vendor: bool = True) -> dict:
     """The CPU restatement of the reference path (oracle/, OpenMP over the tiles of a wave)
     timed on this box's host cores on a bounded sample: one factorisation at (N, B)."""
     from oracle import oracle as orc
@@ -58,6 +61,8 @@ def cpu_baseline(N: int, B: int, seed: int) -> dict:
     dt = time.perf_counter() - t0
     out = {"value": round(N ** 3 / 3.0 / dt / 1e12, 5), "unit": "TFLOP/s", "cores": nthreads, "kind": "port",
            "sample": f"one full factorisation N={N} tile={B} fp64 plgsy(seed={seed}), {dt:.2f} s, info={info}"}
+    if not vendor:
+        return out
     # secondary, clearly labelled: the vendor LAPACK that ships with torch, same N, same threads
     try:
         import torch
@@ -92,6 +97,8 @@ def run_single(a) -> dict:
     N, B = a.N, a.tile
     dt = ch.ChamRealDouble if a.dtype == "f64" else ch.ChamRealFloat
     d = ch.CHAMELEON_Desc_Create(None, dt, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+    probe = ch.mfma_probe(dt, 4)  # the register-only MFMA stream this chip sustains right now (TFLOP/s)
+    kernel = ch.update_kernel_name(dt)
     ch.set_profiling(False)
     for w in range(a.warmup):
         ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
@@ -120,16 +127,18 @@ def run_single(a) -> dict:
     res = ch.residual_plgsy(d, float(N), a.seed) if not a.no_check else None
     ch.CHAMELEON_Desc_Destroy(d)
     return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
-            "residual": res}
+            "residual": res, "probe": probe, "kernel": kernel, "calibration": ch.calibration()}
 
 
 def run_multi(a) -> dict:
     """One process per GPU.  The factorisation is ONE call per step -- CHAMELEON_dpotrf_Tile on the
-    p x q descriptor: the C++ wave loop of libcholmi with its own RCCL communicator (point-to-point
-    groups over xGMI).  torch.distributed (gloo) only bootstraps: it shares the RCCL id, and carries
+    p x q descriptor: the wave walker of libcholmi with its own RCCL communicators (point-to-point
+    groups over xGMI).  torch.distributed (gloo) only bootstraps: it shares the RCCL ids, and carries
     the barriers and the MAX over ranks of the timing.
-    CHOLMI_DIST_BACKEND = rccl (default) | gloo (rehearsal: the same C++ loop, tiles moved by gloo, so
-    that several ranks can share the GPUs that exist) | python (round 1's torch.distributed wave loop)."""
+    CHOLMI_DIST_BACKEND = rccl (default) | gloo (rehearsal: the same walker, tiles moved by gloo, so that
+    several ranks can share the GPUs that exist).  If the library's RCCL transport cannot be built the run
+    goes on over torch.distributed's own NCCL binding and SAYS SO in the line (exchange.backend, exchange.fallback);
+    CHOLMI_DIST_FALLBACK=0 makes that an error instead."""
     import torch
     import torch.distributed as dist
 
@@ -141,42 +150,35 @@ def run_multi(a) -> dict:
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     backend = os.environ.get("CHOLMI_DIST_BACKEND", "rccl")
+    assert backend in ("rccl", "gloo"), backend
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if backend == "python":
-        tb = os.environ.get("CHOLMI_TORCH_BACKEND", "nccl")
-        if tb == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(tb)
-    else:
-        dist.init_process_group("gloo")
+    dist.init_process_group("gloo")
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
-    transport = None
+    fallback = None
     if backend == "rccl":
+        why = ""
         try:
             dd.install_rccl_transport(dist)
             ok = 1
-        except Exception as e:  # keep the run alive: the same C++ loop over torch's own RCCL binding
-            print(f"[bench] rank {rank}: library RCCL transport unavailable ({e}); falling back to torch.distributed/nccl p2p",
-                  file=sys.stderr, flush=True)
+        except Exception as e:
+            why = str(e)[:200]
+            print(f"[bench] rank {rank}: library RCCL transport unavailable ({why})", file=sys.stderr, flush=True)
             ok = 0
         flag = torch.tensor([ok])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
+            if os.environ.get("CHOLMI_DIST_FALLBACK", "1") == "0":
+                raise SystemExit(f"[bench] rank {rank}: the requested transport (rccl) could not be installed: {why}")
             backend = "torch-nccl"
-            transport = dd.TorchTransport(dist, device=local, group=dist.new_group(backend="nccl"))
-            transport.install()
-        factor = eng.potrf_tile
-    elif backend == "gloo":
-        transport = dd.TorchTransport(dist, device=local)
-        transport.install()
-        factor = eng.potrf_tile
+            fallback = why or "another rank failed to build the RCCL transport"
+            tr = dd.TorchTransport(dist, device=local, group=dist.new_group(backend="nccl"))
+            tr.install()
     else:
-        chol = dd.BlockCyclicCholesky(eng, dist, lookahead=True)
-        chol.warm_up()
-        factor = chol.factorize
+        tr = dd.TorchTransport(dist, device=local)
+        tr.install()
+    factor = eng.potrf_tile
     for w in range(max(1, a.warmup)):  # at least one: RCCL connects its peers on first use
         eng.generate(float(a.N), a.seed)
         info = factor()
@@ -193,12 +195,12 @@ def run_multi(a) -> dict:
         dist.barrier()
         elapsed += time.perf_counter() - t0
         assert info == 0, (s, info)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    stats = dd.dist_last_stats() if backend != "python" else None
+    stats = dd.dist_last_stats()
     # the factor of the last timed step, gathered on rank 0 and checked (untimed) against the regenerated matrix
     res = None
-    if not a.no_check and backend != "python":
+    if not a.no_check:
         full = None
         if rank == 0:
             dt = ch.ChamRealDouble if a.dtype == "f64" else ch.ChamRealFloat
@@ -208,7 +210,7 @@ def run_multi(a) -> dict:
             res = ch.residual_plgsy(full, float(a.N), a.seed)
             ch.CHAMELEON_Desc_Destroy(full)
     out = {"elapsed": float(t.item()), "rank": rank, "grid": f"{P}x{Q}", "residual": res, "dist": stats,
-           "backend": backend}
+           "backend": backend, "fallback": fallback}
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -243,13 +245,19 @@ def main() -> int:
     if a.gpus == 1:
         if r["upd_ms"] > 0:
             ach = r["upd_flops"] / (r["upd_ms"] * 1e-3) / 1e12
+            # no accounting may ever put the kernel above what the matrix cores sustain (the probe, +2 % for clock jitter)
+            assert ach <= 1.02 * max(r["probe"], peak), (ach, r["probe"], peak)
             traffic = load_pmc_traffic()
+            static = (traffic["hbm_bytes_per_launch"] * traffic["launches"] / (r["upd_launches"] / a.steps)) \
+                if traffic and traffic.get("N") == a.N and traffic.get("tile") == a.tile else None
             line["roofline"] = {
-                "bound": "mfma", "kernel": "k_trail_update_w8<double,3>" if a.dtype == "f64" else "k_trail_update<float,true>", "achieved": round(ach, 3), "peak": peak,
+                "bound": "mfma", "kernel": r["kernel"], "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                # PMC pass = one factorisation: bytes per launch at THIS run's launch count
-                "traffic": (traffic["hbm_bytes_per_launch"] * traffic["launches"] / (r["upd_launches"] / a.steps))
-                if traffic and traffic.get("N") == a.N and traffic.get("tile") == a.tile else None,
+                # the register-only MFMA stream measured in this run: what the chip sustains, beside the datasheet peak
+                "peak_probe": round(r["probe"], 2), "frac_of_probe": round(ach / r["probe"], 4) if r["probe"] > 0 else None,
+                # HBM bytes per launch from the committed rocprofv3 --pmc pass of this workload (profiles/pmc_traffic.json:
+                # one factorisation, rescaled to THIS run's launch count) -- static, not collected in this run
+                "traffic": static, "traffic_source": "profiles/pmc_traffic.json (committed PMC pass, not measured in this run)" if static else None,
                 "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
                 "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
                 # the launches of a wave run side by side: the HIP-event brackets
@@ -258,12 +266,17 @@ def main() -> int:
                 # overlap twice (profiles/r02_bench_union_busy.txt: sum / union = 1.24, union = brackets)
                 "time_base": "union of concurrent launches",
             }
+            c = r["calibration"]
+            line["config"]["schedule_calibration"] = {"mfma_probe_tflops": [round(c[0], 2), round(c[2], 2)],
+                                                      "diag_step_us": [round(c[1], 1), round(c[3], 1)]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
+            if a.cpu_extra_N and a.cpu_extra_N != a.cpu_N:
+                line["cpu_baseline"]["extra"] = cpu_baseline(a.cpu_extra_N, a.cpu_tile, a.seed, vendor=False)
     if r.get("residual") is not None:
         line["residual"] = r["residual"]
     if r.get("dist"):
-        line["config"]["exchange"] = {"backend": r["backend"], "host_issue_us_per_wave": round(r["dist"]["issue_us_per_wave"], 1),
+        line["config"]["exchange"] = {"backend": r["backend"], "fallback": r.get("fallback"), "host_issue_us_per_wave": round(r["dist"]["issue_us_per_wave"], 1),
                                       "sends_per_rank0": r["dist"]["sends"], "bytes_sent_rank0": r["dist"]["bytes_sent"]}
     print(json.dumps(line), flush=True)
     return 0

@@ -69,20 +69,16 @@ def lib() -> C.CDLL:
         "chol_bench_update": ([vp, i, i, i, C.POINTER(d), C.POINTER(d)], i),
         "chol_desc_local_ptr": ([vp, C.POINTER(C.c_size_t)], vp),
         "chol_desc_local_tiles": ([vp, C.POINTER(i), C.POINTER(i)], i),
-        "chol_wave_potrf": ([vp, i, vp, vp], i),
-        "chol_wave_invert_diag": ([vp, vp, vp], i),
-        "chol_wave_winv_bytes": ([vp], C.c_size_t),
-        "chol_wave_export_winv": ([vp, vp, vp], i),
-        "chol_wave_import_winv": ([vp, vp, vp], i),
-        "chol_wave_trsm": ([vp, i, vp, vp], i),
-        "chol_wave_update": ([vp, i, i, i, pp, C.POINTER(i), i, vp], i),
-        "chol_wave_update_diag": ([vp, i, i, pp, C.POINTER(i), vp], i),
-        "chol_get_info": ([C.POINTER(i)], i),
-        "chol_reset_info": ([], i),
         "chol_set_transport": ([vp], i),
         "chol_transport_rccl_unique_id": ([vp], i),
         "chol_transport_rccl_init": ([vp, i, i], i),
         "chol_transport_rccl_finalize": ([], i),
+        "chol_transport_rccl_version": ([], i),
+        "chol_set_transport_channel": ([i, vp], i),
+        "chol_transport_selftest": ([i, C.c_size_t], i),
+        "chol_dist_rehearse": ([i, i, i, i, i, d, u64, vp, C.POINTER(d)], i),
+        "chol_debug_calibration": ([C.POINTER(d)], i),
+        "chol_debug_update_kernel": ([i, C.c_char_p, i], i),
         "chol_dist_last_stats": ([C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i),
         "chol_dist_factorize_with": ([vp, vp, i, i, i, i, i, i], i),
         "chol_dist_gather_lower": ([vp, vp, i], i),

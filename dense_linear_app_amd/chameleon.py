@@ -257,6 +257,21 @@ def bench_update(desc: Desc, k: int = 0, ablate: int = 0, reps: int = 3) -> tupl
     return ms.value, fl.value / (ms.value * 1e-3) / 1e12
 
 
+def calibration() -> list:
+    """[fp64 MFMA probe TFLOP/s, fp64 diagonal-block step us, fp32 ..., fp32 ...] + the four derived figures the
+    walker's regime switches use (chol_debug_calibration)."""
+    out = (C.c_double * 8)()
+    check("chol_debug_calibration", lib().chol_debug_calibration(out))
+    return list(out)
+
+
+def update_kernel_name(dtype: int = ChamRealDouble) -> str:
+    """Name (as rocprofv3 prints it) of the trailing-update kernel the library launches for `dtype` right now."""
+    buf = C.create_string_buffer(96)
+    check("chol_debug_update_kernel", lib().chol_debug_update_kernel(dtype, buf, len(buf)))
+    return buf.value.decode()
+
+
 def set_profiling(on: bool) -> None:
     lib().chol_set_profiling(1 if on else 0)
 

@@ -19,43 +19,38 @@
 
 using namespace cholmi;
 
-extern "C" int chol_internal_dist_potrf(chol_desc *d, int rank);  // dist.hip
+// dist.hip: the wave walker on a whole tiled matrix -- one GPU (p = q = 1) or this rank's share of a p x q grid
+extern "C" int chol_internal_walk(chol_desc *d, void *base, cholmi::RankCtx *r, int rank);
 extern "C" void chol_internal_dist_finalize(void);
+extern "C" int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm, int ln,
+                                         int i, int j, int m, int n, int p, int q, int my_rank, int nranks);
 
 namespace {
 
-constexpr int SEM_SLOTS = 16384;          // device-side counters: 3 mb/128 + 1 per tile column ...
-constexpr int TILE_SEM_SETS = 8;          // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
-constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
-
 struct Ctx {
   bool inited = false;
-  int device = -1;
   int rank = 0, nranks = 1;
-  hipStream_t s_main = nullptr, s_panel = nullptr, s_trsm = nullptr, s_u1 = nullptr;
-  void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k)
-  size_t winv_bytes = 0;
-  int *d_info = nullptr;
-  int *d_ytab = nullptr;  // per-CU yield requests (kernels.hip: cooperative CU hand-over)
-  int *d_sem = nullptr;   // device-side dependency counters of the panel chain (kernels.hip: sem_wait), or null
-  unsigned tile_sem_next = 0;
+  RankCtx r;              // streams, workspaces, counters, events of this process's rank
+  int *d_ytab = nullptr;  // per-CU yield requests (kernels.hip: cooperative CU hand-over); one per device
   double *d_acc = nullptr;
   void *stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_bytes[3] = {0, 0, 0};
-  std::vector<hipEvent_t> events;
-  bool profiling = false;
-  // stats of the last whole-matrix potrf
-  double total_ms = 0, update_ms = 0, update_flops = 0;
-  int update_launches = 0;
+  void *work = nullptr;   // reusable scratch of lange / potrs (grown on demand)
+  size_t work_bytes = 0;
   std::string last_error;
 };
 Ctx g;
-std::mutex g_mu;
+std::mutex g_mu;     // one ABI call at a time on the context
+std::mutex g_err_mu; // chol_last_error's buffer
 
+void set_error(const char *msg) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g.last_error = msg;
+}
 int fail_hip(hipError_t e, const char *what, int line) {
   char buf[256];
   snprintf(buf, sizeof buf, "%s failed at api.hip:%d: %s", what, line, hipGetErrorString(e));
-  g.last_error = buf;
+  set_error(buf);
   return CHOL_ERR_HIP;
 }
 #define HIPCHECK(call)                                        \
@@ -65,7 +60,7 @@ int fail_hip(hipError_t e, const char *what, int line) {
   } while (0)
 
 int fail(int code, const char *msg) {
-  g.last_error = msg;
+  set_error(msg);
   return code;
 }
 
@@ -74,7 +69,7 @@ inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 // counters for one single-tile POTRF (launch_potrf_tile): a set of 32, rotating so that consecutive
 // factorisations on different streams never share one
 int *tile_sems() {
-  return g.d_sem ? g.d_sem + (size_t)(SEM_SLOTS + 32 * (g.tile_sem_next++ % TILE_SEM_SETS)) * 32 : nullptr;
+  return g.r.d_sem ? g.r.d_sem + (size_t)(SEM_SLOTS + 32 * (g.r.tile_sem_next++ % TILE_SEM_SETS)) * 32 : nullptr;
 }
 
 int ensure_stage(int idx, size_t bytes) {
@@ -88,10 +83,10 @@ int ensure_stage(int idx, size_t bytes) {
 }
 
 int ensure_events(size_t n) {
-  while (g.events.size() < n) {
+  while (g.r.events.size() < n) {
     hipEvent_t e;
     HIPCHECK(hipEventCreate(&e));
-    g.events.push_back(e);
+    g.r.events.push_back(e);
   }
   return 0;
 }
@@ -125,7 +120,7 @@ T *local_tile(const chol_desc *d, void *base, int I, int J) {
 // the context holds the inverses of at most 32 diagonal 128-blocks (tiles up to 4096): every entry
 // that factors, inverts or solves with a tile checks this before any launch writes winv
 bool winv_fits(const chol_desc *d) {
-  return (size_t)(roundup(d->mbi, MACRO) / MACRO) * MACRO * MACRO * d->esize <= g.winv_bytes;
+  return (size_t)(roundup(d->mbi, MACRO) / MACRO) * MACRO * MACRO * d->esize <= g.r.winv_bytes;
 }
 #define CHECK_WINV(d, what) \
   if (!winv_fits(d)) return fail(CHOL_ERR_NOT_SUPPORTED, what ": tile size above 4096")
@@ -155,10 +150,10 @@ int stage_in(const chol_desc *d, int slot, bool identity_pad, Staged *out) {
   int rc = ensure_stage(slot, bytes);
   if (rc) return rc;
   T *dst = reinterpret_cast<T *>(g.stage[slot]);
-  if (B != Bp) HIPCHECK(hipMemsetAsync(dst, 0, bytes, g.s_main));
+  if (B != Bp) HIPCHECK(hipMemsetAsync(dst, 0, bytes, g.r.st[ST_MAIN]));
   HIPCHECK(hipMemcpy2DAsync(dst, (size_t)Bp * sizeof(T), d->mat, (size_t)B * sizeof(T),
-                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.s_main));
-  if (identity_pad) launch_pad_identity<T>(g.s_main, dst, B, Bp);
+                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.r.st[ST_MAIN]));
+  if (identity_pad) launch_pad_identity<T>(g.r.st[ST_MAIN], dst, B, Bp);
   out->dev = dst;
   out->in_place = false;
   return 0;
@@ -169,12 +164,12 @@ int stage_out(const chol_desc *d, const Staged &st) {
   if (st.in_place) return 0;
   const int B = d->mb;
   HIPCHECK(hipMemcpy2DAsync(d->mat, (size_t)B * sizeof(T), st.dev, (size_t)st.ldp * sizeof(T),
-                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.s_main));
+                            (size_t)B * sizeof(T), B, hipMemcpyDefault, g.r.st[ST_MAIN]));
   return 0;
 }
 
 int read_info(int *info) {
-  HIPCHECK(hipMemcpy(info, g.d_info, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(info, g.r.d_info, sizeof(int), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -189,403 +184,6 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
   r.offb = d->n_off + d->gd[jhi];
   r.nb = d->gd[jlo] - d->gd[jhi];
   return r;
-}
-
-// ---- whole-matrix right-looking tiled Cholesky on one GPU --------------------
-// Reference order (C2:506-565): POTRF(k); TRSM(i,k), i > k; SYRK / GEMM (i,j,k), k < j <= i.  Here, per
-// wave k, four streams:
-//   s_panel (high)  POTRF(k) as mb/128 diagonal-block steps
-//   s_trsm  (high)  the TRSM steps of panel k, one 128-column step behind the POTRF steps
-//   s_u1    (mid)   U1(k): column k+1 by panel k -- the diagonal tile (k+1,k+1) first (POTRF(k+1) waits
-//                   for nothing else), then the rest of the column (TRSM(k+1) waits for that)
-//   s_main  (low)   U2(k): the columns beyond, beside U1(k): the two touch different tiles, U1's
-//                   blocks go first and U2's fill whatever U1 -- at most one round of workgroups
-//                   on a mid-size matrix -- leaves idle
-// U1(k) waits for U2(k-1), whose range includes column k+1; U2(k) follows U2(k-1) in stream order.
-// Three regimes by the length of a wave's update against its panel chain: panels in pairs (two per pass of
-// the far columns) while it is more than two chains long; the columns beyond k+1 as a near and a far launch
-// on s_u1 / s_main in the mid waves; and, once it is shorter than the chain, the counter-linked form -- TRSM
-// steps, SYRK slices and the next POTRF launched ahead of time and polling device-side counters, no stream
-// event on the chain (cholmi_internal.h: SyrkPipe; kernels.hip: sem_wait).
-template <typename T>
-int potrf_full_device(chol_desc *d, void *base) {
-  const int nt = d->nt, mb = d->mbi;
-  const long bsiz = d->bsizi;
-  T *M = reinterpret_cast<T *>(base);
-  T *winv = reinterpret_cast<T *>(g.winv);
-  const int nbm = mb / MACRO;
-  enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_NEAR, E_PN0, E_PN1, E_PER_WAVE };
-  enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_HEAD, F_COLS, F_FIXED };
-  int rc = ensure_events((size_t)E_PER_WAVE * nt + F_FIXED + nbm + 1);
-  if (rc) return rc;
-  auto ev = [&](int k, int which) { return g.events[(size_t)E_PER_WAVE * k + which]; };
-  hipEvent_t *fixed = &g.events[(size_t)E_PER_WAVE * nt];
-  hipEvent_t *ev_steps = fixed + F_FIXED;
-  static const bool concurrent = !(getenv("CHOLMI_U1_CONCURRENT") && atoi(getenv("CHOLMI_U1_CONCURRENT")) == 0);
-  // tiles up to this edge are updated by two panels per pass (short K-loops pay the per-block
-  // prologue / epilogue / C traffic twice as often)
-  static const int pair_max_mb = getenv("CHOLMI_PAIR_MAX_MB") ? atoi(getenv("CHOLMI_PAIR_MAX_MB")) : 1024;
-  // ... while a wave's update is at least this many panel chains long: deferring half the updates
-  // leaves the chip short of work once the panel chain is what a wave waits for
-  static const double pair_fac = getenv("CHOLMI_PAIR_FACTOR") ? atof(getenv("CHOLMI_PAIR_FACTOR")) : 2.0;
-  bool paired = false, cols_pending = false;  // paired: this wave belongs to a pair (decided at its even wave)
-  bool had_pairs = false;
-  // experiment, off: keep the chain-critical launches of a chain-bound wave (the head tile's last TRSM step, the
-  // SYRK on the next diagonal tile) on s_panel instead of crossing streams.  Measured -1 ... -2 % at N <= 16384
-  // (the hops it removes were overlapped work, not latency); CHOLMI_CHAIN_INSTREAM=1 enables it.
-  static const bool chain_enabled = getenv("CHOLMI_CHAIN_INSTREAM") && atoi(getenv("CHOLMI_CHAIN_INSTREAM")) != 0;
-  static const double yfac = getenv("CHOLMI_YIELD_FACTOR") ? atof(getenv("CHOLMI_YIELD_FACTOR")) : 3.0;
-  static const bool syrk_pipe = !(getenv("CHOLMI_SYRK_PIPE") && atoi(getenv("CHOLMI_SYRK_PIPE")) == 0);
-  const bool trsm_fused_on = cholmi::g_trsm_fused_min > 0;
-  static const double pipe_fac = getenv("CHOLMI_PIPE_FACTOR") ? atof(getenv("CHOLMI_PIPE_FACTOR")) : 0.7;
-  int open_bracket = -1;                      // odd wave whose profiling bracket is still open
-  // Plain waves of a few rounds of workgroups: the columns beyond k+1 go out as TWO launches, the near
-  // columns [k+2, bnd) on s_u1 behind the column-(k+1) launch and the far ones [bnd, nt) on s_main.  With a
-  // boundary that stays put for several waves each half depends on its own predecessor only (far(k+1) is a
-  // subset of far(k), near(k+1) of near(k)), so the last, partly filled round of one launch runs beside full
-  // rounds of the other chain's next launch instead of beside nothing; and column k+1 -- the next panel --
-  // waits for near(k-1) only.  The boundary moves (then near(k) also waits for far(k-1)) when the near part
-  // has shrunk under 30 % of the wave.
-  static const double halves_max_rounds =
-      getenv("CHOLMI_HALVES_MAX_ROUNDS") ? atof(getenv("CHOLMI_HALVES_MAX_ROUNDS")) : 24.0;
-  int bnd = -1;
-  bool prev_halves = false;
-  std::vector<int> halves_waves;
-  HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
-  if (g.d_ytab) HIPCHECK(hipMemsetAsync(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int), g.s_main));
-  // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): 3 nbm + 1
-  // counters per wave, the last one = workgroups of the last SYRK slice on tile (k+1,k+1)
-  const int sem_per_wave = 3 * nbm + 1;
-  const bool flags = g.d_sem && (long)nt * sem_per_wave <= SEM_SLOTS && concurrent;
-  if (flags) HIPCHECK(hipMemsetAsync(g.d_sem, 0, (size_t)nt * sem_per_wave * 32 * sizeof(int), g.s_main));
-  auto sem = [&](int k, int which) { return g.d_sem + ((size_t)sem_per_wave * k + which) * 32; };
-  const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
-  int wait_target = 0;
-  HIPCHECK(hipEventRecord(fixed[F_START], g.s_main));
-  HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_START], 0));
-  HIPCHECK(hipStreamWaitEvent(g.s_u1, fixed[F_START], 0));
-  HIPCHECK(hipStreamWaitEvent(g.s_trsm, fixed[F_START], 0));  // (its kernels may poll counters zeroed above)
-  const LocalMat C = local_mat(d, base);
-  const double b3 = (double)mb * mb * mb;
-  double upd_flops = 0;
-  int upd_launches = 0;
-  for (int k = 0; k < nt; ++k) {
-    // POTRF on the panel stream, the TRSM steps pipelined behind it on their own stream, which
-    // also needs the rest of column k updated by panel k-1  (C2:510-535)
-    T *lkk = M + ((long)k + (long)k * nt) * bsiz;
-    // (s_trsm needs no event for the start of the wave: its first step waits for the event recorded on
-    // s_panel behind the first diagonal-block step, and a record on s_panel costs the chain ~7 us)
-    if (k > 0) HIPCHECK(hipStreamWaitEvent(g.s_trsm, ev(k - 1, E_U1R), 0));
-    // chain: this wave is about as long as its panel chain -- keep the chain's own launches on s_panel
-    const double mrem = nt - 1 - k;
-    const bool chain = chain_enabled && cholmi::g_intile_small && k + 1 < nt &&
-                       mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < yfac * (nbm * 130e-6 * 1.5);
-    // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite
-    // its set while TRSM(k) still reads the other
-    T *winv_k = winv + (size_t)(k & 1) * (g.winv_bytes / sizeof(T));
-    if ((k & 1) == 0) {
-      const double m = nt - 1 - k;
-      paired = mb <= pair_max_mb && k + 2 < nt &&
-               m * (m + 1) / 2 * (2.0 * b3 / 65e12) >= pair_fac * (nbm * 130e-6 * 1.5);
-    }
-    // Plain (unpaired) wave whose panel chain is (nearly) critical: the SYRK on tile (k+1,k+1) follows
-    // the head tile's TRSM steps slice by slice and the chain's cross-stream edges are device-side
-    // counters (SyrkPipe).
-    const bool plain_yield = mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < yfac * (nbm * 130e-6 * 1.5);
-    hipStream_t su_k = concurrent ? g.s_u1 : g.s_main;
-    // (only while the update is shorter than about a panel chain: the polling workgroups hold CU slots the
-    // update would otherwise use -- measured +10 ... +20 % on the waves between pipe_fac and the yield threshold)
-    const bool chain_bound = mrem * (mrem + 1) / 2 * (2.0 * b3 / 65e12) < pipe_fac * (nbm * 130e-6 * 1.5);
-    const bool pipe = syrk_pipe && flags && !paired && !chain && k + 1 < nt && cholmi::g_intile_small &&
-                      !trsm_fused_on && plain_yield && chain_bound;
-    SyrkPipe sy;
-    if (pipe) {
-      // the tile's earlier writers: U2(k-1), whose range includes column k+1 (or, behind the paired
-      // phase, the column launches of the last pair, which precede this on s_u1 / are joined here)
-      if (concurrent && k > 0) HIPCHECK(hipStreamWaitEvent(su_k, ev(k - 1, E_U2), 0));
-      if (!concurrent && cols_pending) HIPCHECK(hipStreamWaitEvent(su_k, fixed[F_COLS], 0));
-      sy.c = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
-      sy.su = su_k;
-      sy.sem = sem(k, 0);
-    }
-    launch_panel_pipelined<T>(g.s_panel, g.s_trsm, ev_steps, lkk, mb, winv_k, g.d_info, k * mb, lkk + bsiz, bsiz,
-                              nt - 1 - k, fixed[F_HEAD], chain, k > 0 ? ev(k - 1, E_U1R) : nullptr,
-                              pipe ? &sy : nullptr, wait_sem, wait_target);
-    // with device-side edges s_panel waits for no event between waves: POTRF(k+1)'s first step polls the
-    // last slice's counter, which also stands behind TRSM(k) (same stream, earlier), so POTRF(k+2) may
-    // reuse TRSM(k)'s workspace
-    const bool by_flags = pipe;
-    wait_sem = by_flags ? sem(k, 3 * nbm) : nullptr;
-    wait_target = (mb / 64) * (mb / 64 + 1) / 2;
-    // TRSM(k) complete = panel k ready (s_trsm has waited for every POTRF step, and for the head tile's
-    // in-stream step in chain mode).
-    HIPCHECK(hipEventRecord(ev(k, E_PANEL), g.s_trsm));
-    // In chain mode s_panel does not wait for it: POTRF(k+1) needs the SYRK only, and TRSM(k) is over
-    // before POTRF(k+2) reuses its workspace (the head tile's last step of TRSM(k+1) waits for the
-    // earlier ones, which follow TRSM(k) in stream order -- with more than one step per tile).
-    if ((!chain || nbm == 1) && !by_flags) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_PANEL), 0));
-    if (k + 1 >= nt) break;
-    // trailing update (C2:540-560)
-    auto panel_ref = [&](int kk) {
-      PanelRef pr;
-      memset(&pr, 0, sizeof pr);
-      pr.P = 1;
-      pr.base[0] = M + (long)kk * nt * bsiz;
-      return pr;
-    };
-    const PanelRef pan = panel_ref(k);
-    if (paired) {
-      // Panels in pairs (k-1, k), k odd: the far columns' update by the even panel is deferred and
-      // applied together with the odd one in ONE pass of twice the K (k_trail_update, npan = 2).
-      //   even k:  U1(k)  = column k+1 by panel k                                       (s_u1)
-      //   odd  k:  U1'(k) = column k+1, Ca = column k+2, Cb = column k+3 by panels k-1, k  (s_u1, in this order)
-      //            big(k) = the columns from k+4 on by panels k-1, k                      (s_main, beside them)
-      // Every column is written by launches of s_u1 in program order, except by big(); the first
-      // launches of s_u1 on a column big(k) covers are Ca / Cb of wave k+2, which wait for it.
-      // POTRF(k+1) waits for the SYRKs on (k+1,k+1) only, TRSM(k+1) for the rest of column k+1.
-      const bool odd = (k & 1) != 0;
-      const PanelRef prev = panel_ref(odd ? k - 1 : k);
-      const PanelRef *p2 = odd ? &pan : nullptr;       // launches: first `prev`, then `pan` when odd
-      const PanelRef &p1 = odd ? prev : pan;
-      auto rng = [&](int jlo, int jhi) { return col_range(d, jlo < nt ? jlo : nt, jhi < nt ? jhi : nt); };
-      const ColRange c1 = rng(k + 1, k + 2), ca = rng(k + 2, k + 3), cb = rng(k + 3, k + 4), big = rng(k + 4, nt);
-      const int wave_tiles = c1.na + c1.nb + (odd ? ca.na + ca.nb + cb.na + cb.nb + big.na + big.nb : 0);
-      const double t_tile = 2.0 * b3 / 65e12 * (odd ? 2 : 1), t_panel = nbm * 130e-6 * 1.5;
-      const bool yield = (double)wave_tiles * t_tile < yfac * t_panel * (odd ? 2 : 1);
-      hipStream_t su = concurrent ? g.s_u1 : g.s_main;
-      T *ckk = M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz;
-      if (cholmi::g_intile_small) {
-        if (odd) launch_diag_syrk<T>(su, ckk, M + ((long)(k + 1) + (long)(k - 1) * nt) * bsiz, mb);
-        HIPCHECK(hipStreamWaitEvent(su, fixed[F_HEAD], 0));  // the head tile L(k+1,k) is all the last SYRK needs
-        launch_diag_syrk<T>(su, ckk, M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
-      } else {
-        HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
-        launch_trail_update<T>(su, C, d->d_list, c1.off, 0, c1.offb, c1.nb, p1, yield, p2);
-      }
-      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
-      HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
-      HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
-      if (!odd && open_bracket < 0 && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), su));
-      launch_trail_update<T>(su, C, d->d_list, c1.off, c1.na, c1.offb, 0, p1, yield, p2);
-      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
-      int timed = 0;
-      double fl = 0;
-      if (odd) {
-        if (c1.na > 0) ++timed, fl += 2.0 * c1.na;
-        if (k >= 2) HIPCHECK(hipStreamWaitEvent(su, ev(k - 2, E_U2), 0));  // big(k-2) covered these columns
-        launch_trail_update<T>(su, C, d->d_list, ca.off, ca.na, ca.offb, ca.nb, p1, yield, p2);
-        launch_trail_update<T>(su, C, d->d_list, cb.off, cb.na, cb.offb, cb.nb, p1, yield, p2);
-        if (ca.na + ca.nb > 0) ++timed, fl += 2.0 * ca.na + ca.nb;
-        if (cb.na + cb.nb > 0) ++timed, fl += 2.0 * cb.na + cb.nb;
-        HIPCHECK(hipEventRecord(fixed[F_COLS], su));
-        cols_pending = true;
-        had_pairs = true;
-        HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
-        if (g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
-        launch_trail_update<T>(g.s_main, C, d->d_list, big.off, big.na, big.offb, big.nb, p1, yield, p2);
-        if (big.na + big.nb > 0) ++timed, fl += 2.0 * big.na + big.nb;
-        HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
-        // the bracket [P0(k), P1(k)] covers every k_trail_update launch of the pair's update: the
-        // two-panel launches of this wave, which start together, and U1(k+1), which runs beside
-        // big(k); it is closed at the next wave
-        open_bracket = k;
-        upd_launches += timed;
-        upd_flops += 2.0 * fl * b3;  // two panels per pass
-      } else {
-        HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
-        if (g.profiling) {
-          if (open_bracket >= 0) {
-            // waiting for the column launches and for U1(k) on s_main constrains nothing: big(k+1)
-            // needs panel k+1, which comes after all of them
-            HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
-            HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
-            HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
-            HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
-            HIPCHECK(hipEventRecord(ev(k, E_P1), g.s_main));
-          } else {
-            HIPCHECK(hipEventRecord(ev(k, E_P1), su));  // the very first wave: U1(0) alone, bracketed on its stream
-          }
-        }
-        open_bracket = -1;
-        if (c1.na > 0) ++upd_launches, upd_flops += 2.0 * c1.na * b3;
-      }
-      continue;
-    }
-    if (open_bracket >= 0) {  // the paired phase ended on an odd wave: close its bracket
-      if (g.profiling) {
-        HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
-        HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
-      }
-      open_bracket = -1;
-    }
-    const int j2 = k + 2 <= nt ? k + 2 : nt;
-    const ColRange r1 = col_range(d, k + 1, j2), r2 = col_range(d, j2, nt);
-    // Give CUs to the next panel's guest workgroups only when that panel is on the critical
-    // path, i.e. when this wave's update is not much longer than a panel (POTRF ~ (mb/128) x
-    // 130 us, one tile update ~ 2 mb^3 / 65 TFLOP/s); otherwise the polling is pure cost.
-    const double t_tile = 2.0 * b3 / 65e12;
-    const double t_panel = nbm * 130e-6 * 1.5;
-    const bool yield = (double)(r1.na + r1.nb + r2.na + r2.nb) * t_tile < yfac * t_panel;
-    static const bool split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;  // diagnostic
-    const bool split = yield || split_always;
-    hipStream_t su = concurrent ? g.s_u1 : g.s_main;
-    const bool syrk_instream = chain && split && concurrent && !paired;
-    if (syrk_instream) {
-      // the SYRK that releases POTRF(k+1) directly behind the head tile's TRSM on s_panel; the earlier
-      // writers of tile (k+1,k+1) -- the previous waves' updates -- finished long ago in this regime
-      if (k > 0) {
-        HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k - 1, E_U2), 0));
-        HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k - 1, E_U1R), 0));
-      }
-      if (had_pairs) HIPCHECK(hipStreamWaitEvent(g.s_panel, fixed[F_COLS], 0));
-      launch_diag_syrk<T>(g.s_panel, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
-                          M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
-      HIPCHECK(hipEventRecord(ev(k, E_U1D), g.s_panel));
-    }
-    // the SYRK on (k+1,k+1) needs the head tile L(k+1,k) only; everything else the whole panel
-    if (!pipe)
-      HIPCHECK(hipStreamWaitEvent(su, (split && cholmi::g_intile_small && !syrk_instream) ? fixed[F_HEAD] : ev(k, E_PANEL), 0));
-    if (cols_pending) {  // first plain wave after the paired phase: Cb of the last pair wrote column k+2
-      HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
-      cols_pending = false;
-    }
-    // halves: see above
-    const int tiles2 = r2.na + r2.nb;
-    bool halves = halves_max_rounds > 0 && concurrent && !pipe && !syrk_instream && split && nt - 1 - k >= 6 &&
-                  (double)tiles2 * nbm * nbm / 512.0 < halves_max_rounds;
-    bool moved = false;
-    if (halves) {
-      auto tiles_in = [&](int jlo, int jhi) {
-        const ColRange r = col_range(d, jlo, jhi);
-        return r.na + r.nb;
-      };
-      if (!prev_halves || bnd <= k + 2 || tiles_in(k + 2, bnd) * 10 < tiles2 * 3) {
-        int b = k + 3;
-        while (b < nt - 1 && tiles_in(k + 2, b) * 2 < tiles2) ++b;
-        // (the boundary only ever moves right, far(k) stays a subset of far(k-1); should it not, far(k) waits
-        // for near(k-1) as well)
-        if (prev_halves && b < bnd) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k - 1, E_NEAR), 0));
-        bnd = b;
-        moved = true;
-      }
-      if (bnd >= nt) halves = false;
-    }
-    if (prev_halves && !halves) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k - 1, E_NEAR), 0));  // U2(k) covers near(k-1)'s columns
-    if (concurrent) {
-      // column k+1 was in U2(k-1)'s range -- or in near(k-1)'s, which precedes this on s_u1
-      if (k > 0 && !prev_halves) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));
-      HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_PANEL), 0));
-    } else if (g.profiling) {
-      HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
-    }
-    int timed = 0;  // k_trail_update launches inside this wave's profiling bracket
-    if (split) {
-      // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
-      // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
-      if (syrk_instream || pipe) {
-        // (done above: on s_panel / by launch_panel_pipelined)
-      } else if (cholmi::g_intile_small) {
-        launch_diag_syrk<T>(su, M + ((long)(k + 1) + (long)(k + 1) * nt) * bsiz,
-                            M + ((long)(k + 1) + (long)k * nt) * bsiz, mb);
-        HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
-      } else {
-        launch_trail_update<T>(su, C, d->d_list, r1.off, 0, r1.offb, r1.nb, pan, yield);
-        ++timed;
-        HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
-      }
-      HIPCHECK(hipStreamWaitEvent(su, ev(k, E_PANEL), 0));
-      if (halves && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_PN0), su));
-      launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, 0, pan, yield);
-      if (r1.na > 0) ++timed;
-      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
-      if (halves) {
-        const ColRange rn = col_range(d, k + 2, bnd);
-        if (moved && prev_halves) HIPCHECK(hipStreamWaitEvent(su, ev(k - 1, E_U2), 0));  // columns taken over from far(k-1)
-        launch_trail_update<T>(su, C, d->d_list, rn.off, rn.na, rn.offb, rn.nb, pan, yield);
-        ++timed;
-        HIPCHECK(hipEventRecord(ev(k, E_NEAR), su));
-        if (g.profiling) HIPCHECK(hipEventRecord(ev(k, E_PN1), su));
-      }
-    } else {
-      // the update dwarfs the panel: one launch for the whole column (one tail less per wave)
-      launch_trail_update<T>(su, C, d->d_list, r1.off, r1.na, r1.offb, r1.nb, pan, yield);
-      ++timed;
-      HIPCHECK(hipEventRecord(ev(k, E_U1D), su));
-      HIPCHECK(hipEventRecord(ev(k, E_U1R), su));
-    }
-    if (!syrk_instream && !by_flags) HIPCHECK(hipStreamWaitEvent(g.s_panel, ev(k, E_U1D), 0));
-    if (concurrent && g.profiling) HIPCHECK(hipEventRecord(ev(k, E_P0), g.s_main));
-    if (halves) {
-      const ColRange rf = col_range(d, bnd, nt);
-      launch_trail_update<T>(g.s_main, C, d->d_list, rf.off, rf.na, rf.offb, rf.nb, pan, yield);
-      ++timed;
-      halves_waves.push_back(k);
-    } else if (r2.na + r2.nb > 0) {
-      launch_trail_update<T>(g.s_main, C, d->d_list, r2.off, r2.na, r2.offb, r2.nb, pan, yield);
-      ++timed;
-    }
-    HIPCHECK(hipEventRecord(ev(k, E_U2), g.s_main));
-    if (g.profiling) {
-      // the bracket [P0, P1] on s_main covers every k_trail_update launch of the wave: U1(k) started
-      // with U2(k); waiting for its end here constrains nothing (U2(k+1) needs panel k+1, which needs it).
-      // (halves: far(k+1) does NOT need near(k) -- two brackets, [PN0, PN1] on s_u1 for column k+1 and the
-      // near half, and the host takes the union)
-      if (concurrent && !halves) HIPCHECK(hipStreamWaitEvent(g.s_main, ev(k, E_U1R), 0));
-      HIPCHECK(hipEventRecord(ev(k, E_P1), g.s_main));
-    }
-    prev_halves = halves;
-    upd_launches += timed;
-    // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
-    // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
-    upd_flops += (2.0 * r2.na + r2.nb) * b3;
-    upd_flops += (2.0 * r1.na + ((split && cholmi::g_intile_small) ? 0 : r1.nb)) * b3;
-  }
-  if (open_bracket >= 0 && g.profiling) {
-    HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_COLS], 0));
-    HIPCHECK(hipEventRecord(ev(open_bracket, E_P1), g.s_main));
-  }
-  HIPCHECK(hipEventRecord(fixed[F_JOIN], g.s_panel));
-  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_JOIN], 0));
-  HIPCHECK(hipEventRecord(fixed[F_TRSM], g.s_trsm));
-  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_TRSM], 0));
-  HIPCHECK(hipEventRecord(fixed[F_U1END], g.s_u1));
-  HIPCHECK(hipStreamWaitEvent(g.s_main, fixed[F_U1END], 0));
-  HIPCHECK(hipEventRecord(fixed[F_STOP], g.s_main));
-  HIPCHECK(hipStreamSynchronize(g.s_main));
-  float ms = 0;
-  HIPCHECK(hipEventElapsedTime(&ms, fixed[F_START], fixed[F_STOP]));
-  g.total_ms = ms;
-  g.update_flops = upd_flops;
-  g.update_launches = upd_launches;
-  g.update_ms = 0;
-  if (g.profiling) {
-    // union of the brackets (disjoint by construction except around the waves launched as halves)
-    std::vector<std::pair<float, float>> iv;
-    auto add = [&](hipEvent_t a, hipEvent_t b) -> int {
-      float t0 = 0, t1 = 0;
-      HIPCHECK(hipEventElapsedTime(&t0, fixed[F_START], a));
-      HIPCHECK(hipEventElapsedTime(&t1, fixed[F_START], b));
-      if (t1 > t0) iv.emplace_back(t0, t1);
-      return 0;
-    };
-    for (int k = 0; k + 1 < nt; ++k)
-      if ((rc = add(ev(k, E_P0), ev(k, E_P1)))) return rc;
-    for (int k : halves_waves)
-      if ((rc = add(ev(k, E_PN0), ev(k, E_PN1)))) return rc;
-    std::sort(iv.begin(), iv.end());
-    float hi = -1;
-    for (auto &p : iv) {
-      if (p.first > hi) g.update_ms += p.second - p.first;
-      else if (p.second > hi) g.update_ms += p.second - hi;
-      hi = std::max(hi, p.second);
-    }
-  }
-  int info = 0;
-  rc = read_info(&info);
-  if (rc) return rc;
-  if (info > 0 && d->mbi != d->mb)  // stored index -> index in the caller's matrix
-    info = ((info - 1) / d->mbi) * d->mb + (info - 1) % d->mbi + 1;
-  return info;
 }
 
 int build_worklist(chol_desc *d) {
@@ -620,24 +218,24 @@ static int potrf_impl(chol_desc *A, bool upper_staged = false) {
     Staged st;
     int rc = stage_in<T>(A, 0, /*identity_pad=*/true, &st);
     if (rc) return rc;
-    HIPCHECK(hipMemsetAsync(g.d_info, 0, sizeof(int), g.s_main));
+    HIPCHECK(hipMemsetAsync(g.r.d_info, 0, sizeof(int), g.r.st[ST_MAIN]));
     // ChamUpper on a staged tile: A = U^T U with U = L^T -- transpose the staged (identity-padded,
     // multiple-of-128) copy, factor Lower, transpose back: the caller's strict lower triangle comes
     // back exactly as it went in
-    if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
-    launch_potrf_tile<T>(g.s_main, reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.winv),
-                         g.d_info, 0, tile_sems());
-    if (upper_staged) launch_transpose_inplace<T>(g.s_main, reinterpret_cast<T *>(st.dev), 1, st.ldp);
+    if (upper_staged) launch_transpose_inplace<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(st.dev), 1, st.ldp);
+    launch_potrf_tile<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.r.winv),
+                         g.r.d_info, 0, tile_sems());
+    if (upper_staged) launch_transpose_inplace<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(st.dev), 1, st.ldp);
     rc = stage_out<T>(A, st);
     if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(g.s_main));
+    HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
     int info = 0;
     rc = read_info(&info);
     return rc ? rc : info;
   }
-  if (A->p * A->q != 1) return chol_internal_dist_potrf(A, g.rank);  // dist.hip: the block-cyclic wave loop
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
-  if (A->on_device) return potrf_full_device<T>(A, A->mat);
+  // one walker for every whole-matrix descriptor: a single GPU is the p = q = 1 case of the block-cyclic schedule
+  if (A->p * A->q != 1 || A->on_device) return chol_internal_walk(A, A->mat, &g.r, A->p * A->q != 1 ? g.rank : 0);
   // host-resident tiled matrix: stage the whole matrix through HBM
   if (A->padded) return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: padded image over a host buffer");
   const size_t bytes = (size_t)A->mt * A->nt * A->bsiz * sizeof(T);
@@ -649,7 +247,7 @@ static int potrf_impl(chol_desc *A, bool upper_staged = false) {
   int rc = 0;
   hipError_t e = hipMemcpy(dev, A->mat, bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    rc = potrf_full_device<T>(A, dev);
+    rc = chol_internal_walk(A, dev, &g.r, 0);
     if (rc >= 0) e = hipMemcpy(A->mat, dev, bytes, hipMemcpyDeviceToHost);
   }
   (void)hipFree(dev);
@@ -665,13 +263,13 @@ static int trsm_impl(double alpha, chol_desc *L, chol_desc *B) {
   if (rc) return rc;
   rc = stage_in<T>(B, 1, false, &sb);
   if (rc) return rc;
-  T *winv = reinterpret_cast<T *>(g.winv);
-  launch_invert_diag<T>(g.s_main, reinterpret_cast<const T *>(sl.dev), sl.ldp, winv);
-  launch_trsm_panel<T>(g.s_main, reinterpret_cast<T *>(sb.dev), (long)sb.ldp * sb.ldp, 1,
+  T *winv = reinterpret_cast<T *>(g.r.winv);
+  launch_invert_diag<T>(g.r.st[ST_MAIN], reinterpret_cast<const T *>(sl.dev), sl.ldp, winv);
+  launch_trsm_panel<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(sb.dev), (long)sb.ldp * sb.ldp, 1,
                        reinterpret_cast<const T *>(sl.dev), winv, sb.ldp, (T)alpha);
   rc = stage_out<T>(B, sb);
   if (rc) return rc;
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -688,11 +286,11 @@ static int gemm_impl(double alpha, chol_desc *A, chol_desc *B, double beta, chol
   }
   rc = stage_in<T>(C, 2, false, &sc);
   if (rc) return rc;
-  launch_gemm_nt_tile<T>(g.s_main, reinterpret_cast<const T *>(sa.dev), reinterpret_cast<const T *>(sb.dev),
+  launch_gemm_nt_tile<T>(g.r.st[ST_MAIN], reinterpret_cast<const T *>(sa.dev), reinterpret_cast<const T *>(sb.dev),
                          reinterpret_cast<T *>(sc.dev), sc.ldp, (T)alpha, (T)beta, lower);
   rc = stage_out<T>(C, sc);
   if (rc) return rc;
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -716,8 +314,8 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
     return fail(CHOL_ERR_OUT_OF_MEMORY, "potrs_tile: scratch allocation failed");
   }
   T *Z = scr, *Wt = scr + (size_t)nr * nt * bs, *Tt = Wt + bs, *tmp = Tt + (size_t)nt * bs;  // Tt: nt tiles, tmp: nr tiles
-  hipStream_t s = g.s_main;
-  T *winv = reinterpret_cast<T *>(g.winv);
+  hipStream_t s = g.r.st[ST_MAIN];
+  T *winv = reinterpret_cast<T *>(g.r.winv);
   auto Ltile = [&](int i, int j) { return La + ((long)i + (long)j * A->lmt) * bs; };
   auto Ztile = [&](int r, int i) { return Z + ((long)r + (long)i * nr) * bs; };
   // Z(r,i) = B(i,r)^T
@@ -752,19 +350,197 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
   return 0;
 }
 
+// ---- calibration: what the walker's regime switches are measured in (walker.h: WaveCalib) ----------------
+// One 128 x 128 diagonal-block step alone and the register-only MFMA stream, per dtype, timed once per context.
+template <typename T>
+static int time_diag_step(RankCtx *r, double *us) {
+  T *tile = nullptr, *winv = reinterpret_cast<T *>(r->winv);
+  HIPCHECK(hipMalloc(&tile, (size_t)MACRO * MACRO * sizeof(T)));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {
+    // a well-conditioned SPD block: 4 I (the kernel's time does not depend on the values)
+    HIPCHECK(hipMemsetAsync(tile, 0, (size_t)MACRO * MACRO * sizeof(T), r->st[ST_PANEL]));
+    launch_pad_identity<T>(r->st[ST_PANEL], tile, 0, MACRO);
+    HIPCHECK(hipEventRecord(e0, r->st[ST_PANEL]));
+    launch_potrf_tile<T>(r->st[ST_PANEL], tile, MACRO, winv, r->d_info, 0, nullptr);
+    HIPCHECK(hipEventRecord(e1, r->st[ST_PANEL]));
+    HIPCHECK(hipStreamSynchronize(r->st[ST_PANEL]));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(tile);
+  HIPCHECK(hipMemset(r->d_info, 0, sizeof(int)));
+  *us = best * 1e3;
+  return 0;
+}
+
+static int mfma_probe_on(RankCtx *r, int dtype, int waves_per_simd, int iters, double *tflops) {
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, r->device));
+  const int blocks = prop.multiProcessorCount * waves_per_simd;
+  void *buf = nullptr;
+  HIPCHECK(hipMalloc(&buf, (size_t)blocks * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHECK(hipEventRecord(e0, r->st[ST_MAIN]));
+    if (dtype == CHOL_REAL_DOUBLE)
+      launch_mfma_probe<double>(r->st[ST_MAIN], (double *)buf, blocks, iters);
+    else
+      launch_mfma_probe<float>(r->st[ST_MAIN], (float *)buf, blocks, iters);
+    HIPCHECK(hipEventRecord(e1, r->st[ST_MAIN]));
+    HIPCHECK(hipStreamSynchronize(r->st[ST_MAIN]));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double fl = (double)blocks * 4 * iters * 16 * 2048.0;
+    if (rep > 0) best = std::max(best, fl / (ms * 1e-3) / 1e12);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  *tflops = best;
+  return 0;
+}
+
 }  // namespace
+
+namespace cholmi {
+
+void *DevPool::get(size_t bytes) {
+  for (auto &b : blks)
+    if (!b.used && b.bytes >= bytes) {
+      b.used = true;
+      return b.p;
+    }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  blks.push_back({p, bytes, true});
+  return p;
+}
+void DevPool::free_all() {
+  for (auto &b : blks) (void)hipFree(b.p);
+  blks.clear();
+}
+
+RankCtx *main_rank_ctx() { return &g.r; }
+int main_rank(int *nranks) {
+  if (nranks) *nranks = g.nranks;
+  return g.rank;
+}
+
+// Streams, workspaces, counters of one rank on `device` (already current).  calib_from: take the measured
+// rates from another context of the same device instead of measuring again.
+int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from) {
+  r->device = device;
+  int lo = 0, hi = 0;
+  HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_MAIN], hipStreamNonBlocking, lo));
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_PANEL], hipStreamNonBlocking, hi));
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_TRSM], hipStreamNonBlocking, hi));
+  // the update of column k+1 (what the next panel waits for) runs beside the rest of the wave's
+  // update, ahead of it in priority
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_U1], hipStreamNonBlocking, lo - 1 > hi ? lo - 1 : hi));
+  // the two communication streams of a p x q factorisation (walker.h); idle otherwise
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_CX], hipStreamNonBlocking, hi));
+  HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_PX], hipStreamNonBlocking, hi));
+  r->winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
+  HIPCHECK(hipMalloc(&r->winv, 2 * r->winv_bytes));  // two sets: the walker alternates them by wave parity
+  HIPCHECK(hipMalloc(&r->d_info, sizeof(int)));
+  HIPCHECK(hipMemset(r->d_info, 0, sizeof(int)));
+  {
+    // Device-side edges of the panel chain: usable only if a kernel polling on one of the panel streams does
+    // not keep the others from running (streams that share a hardware queue would deadlock until the poll's
+    // bound).  Probed once, both ways, consumer launched first.
+    const char *e = getenv("CHOLMI_DEVICE_FLAGS");
+    if (!e || atoi(e) != 0) {
+      HIPCHECK(hipMalloc(&r->d_sem, SEM_INTS * sizeof(int)));
+      HIPCHECK(hipMemset(r->d_sem, 0, SEM_INTS * sizeof(int)));
+      bool ok = true;
+      const hipStream_t pairs[4][2] = {{r->st[ST_TRSM], r->st[ST_PANEL]}, {r->st[ST_U1], r->st[ST_TRSM]},
+                                       {r->st[ST_PANEL], r->st[ST_U1]}, {r->st[ST_PANEL], r->st[ST_TRSM]}};
+      for (int t = 0; t < 4 && ok; ++t) {  // {consumer, producer}: the three edges of SyrkPipe, and sp / st the other way
+        int *sem = r->d_sem + 64 * t, *res = r->d_sem + 64 * t + 32;
+        cholmi::launch_sem_probe(pairs[t][0], pairs[t][1], sem, res);
+        HIPCHECK(hipStreamSynchronize(pairs[t][0]));
+        HIPCHECK(hipStreamSynchronize(pairs[t][1]));
+        int v = 0;
+        HIPCHECK(hipMemcpy(&v, res, sizeof(int), hipMemcpyDeviceToHost));
+        ok = (v == 1);
+      }
+      if (!ok) {
+        (void)hipFree(r->d_sem);
+        r->d_sem = nullptr;
+      } else {
+        HIPCHECK(hipMemset(r->d_sem, 0, 1024 * sizeof(int)));
+      }
+    }
+  }
+  if (calib_from) {
+    for (int i = 0; i < 2; ++i) r->probe_tflops[i] = calib_from->probe_tflops[i], r->diag_us[i] = calib_from->diag_us[i];
+    return 0;
+  }
+  // CHOLMI_CALIB="tf64,us64,tf32,us32": fixed values instead of measured ones (reproducible schedules)
+  if (const char *e = getenv("CHOLMI_CALIB")) {
+    double v[4];
+    if (sscanf(e, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4) {
+      r->probe_tflops[0] = v[0], r->diag_us[0] = v[1], r->probe_tflops[1] = v[2], r->diag_us[1] = v[3];
+      return 0;
+    }
+  }
+  int rc = mfma_probe_on(r, CHOL_REAL_DOUBLE, 4, 1000, &r->probe_tflops[0]);  // (also brings the clocks up)
+  if (!rc) rc = mfma_probe_on(r, CHOL_REAL_FLOAT, 4, 2000, &r->probe_tflops[1]);
+  if (!rc) rc = time_diag_step<double>(r, &r->diag_us[0]);
+  if (!rc) rc = time_diag_step<float>(r, &r->diag_us[1]);
+  return rc;
+}
+
+void rank_ctx_destroy(RankCtx *r) {
+  for (auto e : r->events) (void)hipEventDestroy(e);
+  r->events.clear();
+  r->pool.free_all();
+  if (r->winv) (void)hipFree(r->winv);
+  if (r->d_info) (void)hipFree(r->d_info);
+  if (r->d_sem) (void)hipFree(r->d_sem);
+  r->winv = nullptr;
+  r->d_info = nullptr;
+  r->d_sem = nullptr;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (r->st[i]) (void)hipStreamDestroy(r->st[i]);
+    r->st[i] = nullptr;
+  }
+}
+
+}  // namespace cholmi
 
 extern "C" {
 
 int chol_internal_fail(int code, const char *msg) { return fail(code, msg); }
 
-const char *chol_version(void) { return "cholmi 0.2 (gfx950)"; }
-const char *chol_last_error(void) { return g.last_error.c_str(); }
+const char *chol_version(void) { return "cholmi 0.3 (gfx950)"; }
+
+// (a copy per thread: the buffer behind the pointer never changes under the caller)
+const char *chol_last_error(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  copy = g.last_error;
+  return copy.c_str();
+}
 
 int chol_set_device(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g.inited && device != g.device) return fail(-1, "chol_set_device after chol_init");
-  g.device = device;
+  if (g.inited && device != g.r.device) return fail(-1, "chol_set_device after chol_init");
+  g.r.device = device;
   return 0;
 }
 
@@ -787,20 +563,12 @@ int chol_init(int ncpu, int ngpu) {
     (void)hipGetLastError();
     return fail(CHOL_ERR_NO_GPU, "chol_init: no HIP device visible");
   }
-  if (g.device < 0) {
+  if (g.r.device < 0) {
     const char *lr = getenv("LOCAL_RANK");
-    g.device = lr ? atoi(lr) % count : 0;
+    g.r.device = lr ? atoi(lr) % count : 0;
   }
-  if (g.device >= count) return fail(CHOL_ERR_NO_GPU, "chol_init: device index out of range");
-  HIPCHECK(hipSetDevice(g.device));
-  int lo = 0, hi = 0;
-  HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  HIPCHECK(hipStreamCreateWithPriority(&g.s_main, hipStreamNonBlocking, lo));
-  HIPCHECK(hipStreamCreateWithPriority(&g.s_panel, hipStreamNonBlocking, hi));
-  HIPCHECK(hipStreamCreateWithPriority(&g.s_trsm, hipStreamNonBlocking, hi));
-  // the update of column k+1 (what the next panel waits for) runs beside the rest of the wave's
-  // update, ahead of it in priority
-  HIPCHECK(hipStreamCreateWithPriority(&g.s_u1, hipStreamNonBlocking, lo - 1 > hi ? lo - 1 : hi));
+  if (g.r.device >= count) return fail(CHOL_ERR_NO_GPU, "chol_init: device index out of range");
+  HIPCHECK(hipSetDevice(g.r.device));
   if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
@@ -808,7 +576,7 @@ int chol_init(int ncpu, int ngpu) {
     // grids that may poll a counter themselves: few enough that, one per CU in the worst case, most CUs
     // stay free of pollers (kernels.hip: k_sem_gate); on a small partition every grid waits behind a gate
     hipDeviceProp_t prop;
-    HIPCHECK(hipGetDeviceProperties(&prop, g.device));
+    HIPCHECK(hipGetDeviceProperties(&prop, g.r.device));
     const int room = (prop.multiProcessorCount - 32) / 4;
     cholmi::g_poll_max_wgs = room < 0 ? 0 : (room < 48 ? room : 48);
   }
@@ -818,10 +586,6 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);
   if (const char *e = getenv("CHOLMI_LATE_DMA")) cholmi::g_late_dma = atoi(e);
   if (const char *e = getenv("CHOLMI_F32_W8")) cholmi::g_f32_w8 = atoi(e);
-  g.winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
-  HIPCHECK(hipMalloc(&g.winv, 2 * g.winv_bytes));  // two sets: the walker alternates them by wave parity
-  HIPCHECK(hipMalloc(&g.d_info, sizeof(int)));
-  HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
   HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
   {
     const char *e = getenv("CHOLMI_YIELD");
@@ -831,31 +595,8 @@ int chol_init(int ncpu, int ngpu) {
       cholmi::g_ytab = g.d_ytab;
     }
   }
-  {
-    // Device-side edges of the panel chain: usable only if a kernel polling on one of the two panel
-    // streams does not keep the other from running (streams that share a hardware queue would
-    // deadlock until the poll's bound).  Probed once, both ways, consumer launched first.
-    const char *e = getenv("CHOLMI_DEVICE_FLAGS");
-    if (!e || atoi(e) != 0) {
-      HIPCHECK(hipMalloc(&g.d_sem, SEM_INTS * sizeof(int)));
-      HIPCHECK(hipMemset(g.d_sem, 0, SEM_INTS * sizeof(int)));
-      bool ok = true;
-      const hipStream_t pairs[4][2] = {{g.s_trsm, g.s_panel}, {g.s_u1, g.s_trsm}, {g.s_panel, g.s_u1}, {g.s_panel, g.s_trsm}};
-      for (int t = 0; t < 4 && ok; ++t) {  // {consumer, producer}: the three edges of SyrkPipe, and sp / st the other way
-        int *sem = g.d_sem + 64 * t, *res = g.d_sem + 64 * t + 32;
-        cholmi::launch_sem_probe(pairs[t][0], pairs[t][1], sem, res);
-        HIPCHECK(hipStreamSynchronize(pairs[t][0]));
-        HIPCHECK(hipStreamSynchronize(pairs[t][1]));
-        int r = 0;
-        HIPCHECK(hipMemcpy(&r, res, sizeof(int), hipMemcpyDeviceToHost));
-        ok = (r == 1);
-      }
-      if (!ok) {
-        (void)hipFree(g.d_sem);
-        g.d_sem = nullptr;
-      }
-    }
-  }
+  int rc = rank_ctx_create(&g.r, g.r.device, nullptr);
+  if (rc) return rc;
   g.inited = true;
   return 0;
 }
@@ -865,35 +606,32 @@ int chol_finalize(void) {
   if (!g.inited) return 0;
   (void)hipDeviceSynchronize();
   chol_internal_dist_finalize();
-  for (auto e : g.events) (void)hipEventDestroy(e);
-  g.events.clear();
   for (int i = 0; i < 3; ++i) {
     if (g.stage[i]) (void)hipFree(g.stage[i]);
     g.stage[i] = nullptr;
     g.stage_bytes[i] = 0;
   }
-  (void)hipFree(g.winv);
-  (void)hipFree(g.d_info);
+  if (g.work) (void)hipFree(g.work);
+  g.work = nullptr;
+  g.work_bytes = 0;
   (void)hipFree(g.d_acc);
   if (g.d_ytab) (void)hipFree(g.d_ytab);
   g.d_ytab = nullptr;
-  if (g.d_sem) (void)hipFree(g.d_sem);
-  g.d_sem = nullptr;
   cholmi::g_ytab = nullptr;
-  (void)hipStreamDestroy(g.s_main);
-  (void)hipStreamDestroy(g.s_panel);
-  (void)hipStreamDestroy(g.s_trsm);
-  (void)hipStreamDestroy(g.s_u1);
-  g.winv = nullptr;
-  g.d_info = nullptr;
+  rank_ctx_destroy(&g.r);
   g.d_acc = nullptr;
-  g.s_main = g.s_panel = g.s_trsm = g.s_u1 = nullptr;
   g.inited = false;
   return 0;
 }
 
 int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm,
                      int ln, int i, int j, int m, int n, int p, int q) {
+  return chol_internal_desc_create(desc, mat, dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q, g.rank, g.nranks);
+}
+
+// (rank, nranks: chol_set_rank's values -- or those of one rank of the one-GPU rehearsal, dist.hip)
+int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm, int ln,
+                              int i, int j, int m, int n, int p, int q, int my_rank, int nranks) {
   if (!desc) return fail(-1, "desc_create: desc is NULL");
   *desc = nullptr;
   if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-3, "desc_create: dtype");
@@ -923,7 +661,7 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     ln = n;
     i = j = 0;
   }
-  if (p * q != 1 && p * q != g.nranks)
+  if (p * q != 1 && p * q != nranks)
     return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: p*q must equal the number of ranks (chol_set_rank)");
   chol_desc *d = new chol_desc();
   d->dtype = dtype; d->mb = mb; d->nb = nb; d->bsiz = bsiz; d->lm = lm; d->ln = ln;
@@ -931,7 +669,7 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
   d->esize = dtype == CHOL_REAL_DOUBLE ? 8 : 4;
   d->mt = (lm + mb - 1) / mb;
   d->nt = (ln + nb - 1) / nb;
-  const int rank = (p * q == 1) ? 0 : g.rank;
+  const int rank = (p * q == 1) ? 0 : my_rank;
   d->prow = rank / q;
   d->pcol = rank % q;
   d->lmt = (d->mt - d->prow + p - 1) / p;
@@ -974,13 +712,13 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
     if (d->padded && lm == ln) {  // zero everywhere, identity on the diagonal tiles' diagonals
       const LocalMat Lm = local_mat(d, d->mat);
       if (dtype == CHOL_REAL_DOUBLE)
-        launch_plgsy<double>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
+        launch_plgsy<double>(g.r.st[ST_MAIN], Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
       else
-        launch_plgsy<float>(g.s_main, Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
-      (void)hipStreamSynchronize(g.s_main);
+        launch_plgsy<float>(g.r.st[ST_MAIN], Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
+      (void)hipStreamSynchronize(g.r.st[ST_MAIN]);
     } else {  // library-owned storage starts at zero (tiles a one-sided dplgsy does not touch)
-      (void)hipMemsetAsync(d->mat, 0, bytes, g.s_main);
-      (void)hipStreamSynchronize(g.s_main);
+      (void)hipMemsetAsync(d->mat, 0, bytes, g.r.st[ST_MAIN]);
+      (void)hipStreamSynchronize(g.r.st[ST_MAIN]);
     }
   }
   if (multi || d->padded) {
@@ -1036,14 +774,14 @@ int chol_potrf_tile(int uplo, chol_desc_t *A) {
     return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A, true) : potrf_impl<float>(A, true);
   auto flip = [&]() {
     if (A->dtype == CHOL_REAL_DOUBLE)
-      launch_transpose_inplace<double>(g.s_main, (double *)A->mat, A->nt, A->mbi);
+      launch_transpose_inplace<double>(g.r.st[ST_MAIN], (double *)A->mat, A->nt, A->mbi);
     else
-      launch_transpose_inplace<float>(g.s_main, (float *)A->mat, A->nt, A->mbi);
+      launch_transpose_inplace<float>(g.r.st[ST_MAIN], (float *)A->mat, A->nt, A->mbi);
   };
   flip();
   const int rc = A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
   flip();
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return rc;
 }
 
@@ -1110,10 +848,10 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
   std::lock_guard<std::mutex> lk(g_mu);
   const LocalMat L = local_mat(A, A->mat);
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_plgsy<double>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
+    launch_plgsy<double>(g.r.st[ST_MAIN], L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
   else
-    launch_plgsy<float>(g.s_main, L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+    launch_plgsy<float>(g.r.st[ST_MAIN], L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -1155,10 +893,10 @@ int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
   std::lock_guard<std::mutex> lk(g_mu);
   const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_lacpy<double>(g.s_main, geo_of(A), side, (const double *)A->mat, (double *)B->mat);
+    launch_lacpy<double>(g.r.st[ST_MAIN], geo_of(A), side, (const double *)A->mat, (double *)B->mat);
   else
-    launch_lacpy<float>(g.s_main, geo_of(A), side, (const float *)A->mat, (float *)B->mat);
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+    launch_lacpy<float>(g.r.st[ST_MAIN], geo_of(A), side, (const float *)A->mat, (float *)B->mat);
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -1172,10 +910,10 @@ int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_d
   if (!same_geometry(A, B)) return fail(-5, "geadd_tile: descriptors differ in shape, tiling or type");
   std::lock_guard<std::mutex> lk(g_mu);
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_geadd<double>(g.s_main, geo_of(A), alpha, (const double *)A->mat, beta, (double *)B->mat);
+    launch_geadd<double>(g.r.st[ST_MAIN], geo_of(A), alpha, (const double *)A->mat, beta, (double *)B->mat);
   else
-    launch_geadd<float>(g.s_main, geo_of(A), alpha, (const float *)A->mat, beta, (float *)B->mat);
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+    launch_geadd<float>(g.r.st[ST_MAIN], geo_of(A), alpha, (const float *)A->mat, beta, (float *)B->mat);
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -1197,12 +935,12 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
   double *work = nullptr;
   HIPCHECK(hipMalloc(&work, (size_t)(std::max(ge.m, ge.n) + 2) * sizeof(double)));
   if (A->dtype == CHOL_REAL_DOUBLE)
-    launch_lange<double>(g.s_main, ge, kind, (const double *)A->mat, work);
+    launch_lange<double>(g.r.st[ST_MAIN], ge, kind, (const double *)A->mat, work);
   else
-    launch_lange<float>(g.s_main, ge, kind, (const float *)A->mat, work);
+    launch_lange<float>(g.r.st[ST_MAIN], ge, kind, (const float *)A->mat, work);
   double v = 0;
-  hipError_t e = hipMemcpyAsync(&v, work, sizeof(double), hipMemcpyDeviceToHost, g.s_main);
-  if (e == hipSuccess) e = hipStreamSynchronize(g.s_main);
+  hipError_t e = hipMemcpyAsync(&v, work, sizeof(double), hipMemcpyDeviceToHost, g.r.st[ST_MAIN]);
+  if (e == hipSuccess) e = hipStreamSynchronize(g.r.st[ST_MAIN]);
   (void)hipFree(work);
   if (e != hipSuccess) return fail_hip(e, "lange_tile", __LINE__);
   *value = kind == 3 ? std::sqrt(v) : v;
@@ -1229,13 +967,13 @@ int chol_lauum_tile(int uplo, chol_desc_t *A) {
   ge.m = (long)ge.lmt * ge.mbs;
   ge.n = (long)ge.lnt * ge.mbs;
   if (A->dtype == CHOL_REAL_DOUBLE) {
-    launch_lauum_lower<double>(g.s_main, (const double *)A->mat, (double *)tmp, A->nt, A->mbi);
-    launch_lacpy<double>(g.s_main, ge, 1, (const double *)tmp, (double *)A->mat);
+    launch_lauum_lower<double>(g.r.st[ST_MAIN], (const double *)A->mat, (double *)tmp, A->nt, A->mbi);
+    launch_lacpy<double>(g.r.st[ST_MAIN], ge, 1, (const double *)tmp, (double *)A->mat);
   } else {
-    launch_lauum_lower<float>(g.s_main, (const float *)A->mat, (float *)tmp, A->nt, A->mbi);
-    launch_lacpy<float>(g.s_main, ge, 1, (const float *)tmp, (float *)A->mat);
+    launch_lauum_lower<float>(g.r.st[ST_MAIN], (const float *)A->mat, (float *)tmp, A->nt, A->mbi);
+    launch_lacpy<float>(g.r.st[ST_MAIN], ge, 1, (const float *)tmp, (float *)A->mat);
   }
-  hipError_t e = hipStreamSynchronize(g.s_main);
+  hipError_t e = hipStreamSynchronize(g.r.st[ST_MAIN]);
   (void)hipFree(tmp);
   if (e != hipSuccess) return fail_hip(e, "lauum_tile", __LINE__);
   return 0;
@@ -1332,18 +1070,18 @@ static int residual_common(chol_desc_t *L, double bump, unsigned long long seed,
   double *rows = nullptr;
   if (rel_inf) {
     HIPCHECK(hipMalloc(&rows, 2 * (size_t)n * sizeof(double)));
-    HIPCHECK(hipMemsetAsync(rows, 0, 2 * (size_t)n * sizeof(double), g.s_main));
+    HIPCHECK(hipMemsetAsync(rows, 0, 2 * (size_t)n * sizeof(double), g.r.st[ST_MAIN]));
   }
-  HIPCHECK(hipMemsetAsync(g.d_acc, 0, 2 * sizeof(double), g.s_main));
+  HIPCHECK(hipMemsetAsync(g.d_acc, 0, 2 * sizeof(double), g.r.st[ST_MAIN]));
   if (L->dtype == CHOL_REAL_DOUBLE)
-    launch_residual<double>(g.s_main, reinterpret_cast<const double *>(L->mat), L->nt, L->mbi, bump, seed,
+    launch_residual<double>(g.r.st[ST_MAIN], reinterpret_cast<const double *>(L->mat), L->nt, L->mbi, bump, seed,
                             g.d_acc, L->mb, n, rows);
   else
-    launch_residual<float>(g.s_main, reinterpret_cast<const float *>(L->mat), L->nt, L->mbi, bump, seed,
+    launch_residual<float>(g.r.st[ST_MAIN], reinterpret_cast<const float *>(L->mat), L->nt, L->mbi, bump, seed,
                            g.d_acc, L->mb, n, rows);
   double h[2];
-  HIPCHECK(hipMemcpyAsync(h, g.d_acc, sizeof h, hipMemcpyDeviceToHost, g.s_main));
-  HIPCHECK(hipStreamSynchronize(g.s_main));
+  HIPCHECK(hipMemcpyAsync(h, g.d_acc, sizeof h, hipMemcpyDeviceToHost, g.r.st[ST_MAIN]));
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   if (rel_fro) *rel_fro = sqrt(h[0]) / sqrt(h[1]);
   if (rel_inf) {
     std::vector<double> hr(2 * (size_t)n);
@@ -1370,15 +1108,15 @@ int chol_residual_plgsy_inf(chol_desc_t *L, double bump, unsigned long long seed
 
 // ---------------------------------------------------------------- instrumentation
 int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launches, double *update_flops) {
-  if (total_ms) *total_ms = g.total_ms;
-  if (update_ms) *update_ms = g.update_ms;
-  if (update_launches) *update_launches = g.update_launches;
-  if (update_flops) *update_flops = g.update_flops;
+  if (total_ms) *total_ms = g.r.total_ms;
+  if (update_ms) *update_ms = g.r.update_ms;
+  if (update_launches) *update_launches = g.r.update_launches;
+  if (update_flops) *update_flops = g.r.update_flops;
   return 0;
 }
 
 int chol_set_profiling(int on) {
-  g.profiling = on != 0;
+  g.r.profiling = on != 0;
   return 0;
 }
 
@@ -1402,15 +1140,15 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   cholmi::g_ablate = ablate;
   float best = 1e30f;
   for (int r = 0; r <= reps; ++r) {
-    HIPCHECK(hipEventRecord(g.events[0], g.s_main));
+    HIPCHECK(hipEventRecord(g.r.events[0], g.r.st[ST_MAIN]));
     if (d->dtype == CHOL_REAL_DOUBLE)
-      launch_trail_update<double>(g.s_main, C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
+      launch_trail_update<double>(g.r.st[ST_MAIN], C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
     else
-      launch_trail_update<float>(g.s_main, C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
-    HIPCHECK(hipEventRecord(g.events[1], g.s_main));
-    HIPCHECK(hipStreamSynchronize(g.s_main));
+      launch_trail_update<float>(g.r.st[ST_MAIN], C, d->d_list, rr.off, rr.na, rr.offb, rr.nb, pan);
+    HIPCHECK(hipEventRecord(g.r.events[1], g.r.st[ST_MAIN]));
+    HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
     float t = 0;
-    HIPCHECK(hipEventElapsedTime(&t, g.events[0], g.events[1]));
+    HIPCHECK(hipEventElapsedTime(&t, g.r.events[0], g.r.events[1]));
     if (r > 0 && t < best) best = t;
   }
   cholmi::g_ablate = 0;
@@ -1446,170 +1184,34 @@ int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "mfma_probe before chol_init");
   if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(-2, "mfma_probe: arguments");
   std::lock_guard<std::mutex> lk(g_mu);
-  hipDeviceProp_t prop;
-  HIPCHECK(hipGetDeviceProperties(&prop, g.device));
-  const int blocks = prop.multiProcessorCount * waves_per_simd, iters = 4000;
-  int rc = ensure_stage(0, (size_t)blocks * 256 * sizeof(double));
-  if (rc) return rc;
-  rc = ensure_events(2);
-  if (rc) return rc;
-  double best = 0;
-  for (int rep = 0; rep < 4; ++rep) {
-    HIPCHECK(hipEventRecord(g.events[0], g.s_main));
-    if (dtype == CHOL_REAL_DOUBLE)
-      launch_mfma_probe<double>(g.s_main, (double *)g.stage[0], blocks, iters);
-    else
-      launch_mfma_probe<float>(g.s_main, (float *)g.stage[0], blocks, iters);
-    HIPCHECK(hipEventRecord(g.events[1], g.s_main));
-    HIPCHECK(hipStreamSynchronize(g.s_main));
-    float ms = 0;
-    HIPCHECK(hipEventElapsedTime(&ms, g.events[0], g.events[1]));
-    const double fl = (double)blocks * 4 * iters * 16 * 2048.0;
-    if (rep > 0) best = std::max(best, fl / (ms * 1e-3) / 1e12);
+  return mfma_probe_on(&g.r, dtype, waves_per_simd, 4000, tflops);
+}
+
+int chol_debug_update_kernel(int dtype, char *buf, int buflen) {
+  if (!buf || buflen < 8) return fail(-2, "debug_update_kernel: buffer");
+  const bool f64 = dtype == CHOL_REAL_DOUBLE;
+  if (!f64 && dtype != CHOL_REAL_FLOAT) return fail(-1, "debug_update_kernel: dtype");
+  // mirrors the dispatch of launch_trail_update (kernels.hip)
+  if (cholmi::g_variant >= 2 && !f64 && cholmi::g_f32_w8) snprintf(buf, buflen, "cholmi::k_trail_update_w8f");
+  else if (cholmi::g_variant >= 2 && f64) snprintf(buf, buflen, "cholmi::k_trail_update_w8<double, %d>", std::min(3, cholmi::g_variant - 2));
+  else if (cholmi::g_variant == 1) snprintf(buf, buflen, "cholmi::k_trail_update<%s, false, false>", f64 ? "double" : "float");
+  else snprintf(buf, buflen, "cholmi::k_trail_update<%s, true, %s>", f64 ? "double" : "float", cholmi::g_late_dma ? "true" : "false");
+  return 0;
+}
+
+// What the walker's regime switches are measured in, as taken at chol_init (or from CHOLMI_CALIB):
+// out[0..3] = fp64 MFMA probe [TFLOP/s], fp64 diagonal-block step [us], fp32 probe, fp32 step;
+// out[4..7] = the derived per-dtype update rate [TFLOP/s] and panel step [us] the walker uses (walker.h: WaveCalib)
+int chol_debug_calibration(double *out8) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "debug_calibration before chol_init");
+  if (!out8) return fail(-1, "debug_calibration: NULL");
+  for (int i = 0; i < 2; ++i) {
+    out8[2 * i] = g.r.probe_tflops[i];
+    out8[2 * i + 1] = g.r.diag_us[i];
+    out8[4 + 2 * i] = g.r.probe_tflops[i] * CHOLMI_UPDATE_EFF;
+    out8[5 + 2 * i] = g.r.diag_us[i] * CHOLMI_STEP_FACTOR;
   }
-  *tflops = best;
   return 0;
-}
-
-// ---------------------------------------------------------------- distributed building blocks
-int chol_get_info(int *info) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "get_info before chol_init");
-  HIPCHECK(hipDeviceSynchronize());
-  return read_info(info);
-}
-
-int chol_reset_info(void) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "reset_info before chol_init");
-  HIPCHECK(hipMemset(g.d_info, 0, sizeof(int)));
-  return 0;
-}
-
-int chol_wave_potrf(chol_desc_t *d, int k, void *lkk, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_potrf before chol_init");
-  if (!d || !lkk) return fail(-1, "wave_potrf: NULL");
-  CHECK_WINV(d, "wave_potrf");
-  hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_potrf_tile<double>(s, (double *)lkk, d->mbi, (double *)g.winv, g.d_info, k * d->mbi, tile_sems());
-  else
-    launch_potrf_tile<float>(s, (float *)lkk, d->mbi, (float *)g.winv, g.d_info, k * d->mbi, tile_sems());
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
-int chol_wave_invert_diag(chol_desc_t *d, void *lkk, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_invert_diag before chol_init");
-  if (!d || !lkk) return fail(-1, "wave_invert_diag: NULL");
-  CHECK_WINV(d, "wave_invert_diag");
-  hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_invert_diag<double>(s, (const double *)lkk, d->mbi, (double *)g.winv);
-  else
-    launch_invert_diag<float>(s, (const float *)lkk, d->mbi, (float *)g.winv);
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
-// Move the 128-block inverses of the current L(k,k) (written by chol_wave_potrf) out of /
-// into the context workspace, so that they can travel with the broadcast of L(k,k) instead of
-// being recomputed on every rank of the process column.
-size_t chol_wave_winv_bytes(chol_desc_t *d) {
-  return d ? (size_t)(d->mbi / MACRO) * MACRO * MACRO * d->esize : 0;
-}
-
-int chol_wave_export_winv(chol_desc_t *d, void *dst, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_export_winv before chol_init");
-  if (!d || !dst) return fail(-1, "wave_export_winv: NULL");
-  HIPCHECK(hipMemcpyAsync(dst, g.winv, chol_wave_winv_bytes(d), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  return 0;
-}
-
-int chol_wave_import_winv(chol_desc_t *d, const void *src, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_import_winv before chol_init");
-  if (!d || !src) return fail(-1, "wave_import_winv: NULL");
-  HIPCHECK(hipMemcpyAsync(g.winv, src, chol_wave_winv_bytes(d), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  return 0;
-}
-
-int chol_wave_trsm(chol_desc_t *d, int k, const void *lkk, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_trsm before chol_init");
-  if (!d || !lkk) return fail(-1, "wave_trsm: NULL");
-  CHECK_WINV(d, "wave_trsm");
-  if (k % d->q != d->pcol) return 0;  // this process column holds no tile of panel k
-  hipStream_t s = (hipStream_t)stream;
-  const int il0 = (k + d->p - d->prow) / d->p;  // first local row with global index > k
-  const int cnt = d->lmt - il0;
-  if (cnt <= 0) return 0;
-  const size_t off = ((size_t)il0 + (size_t)(k / d->q) * d->lmt) * (size_t)d->bsizi;
-  if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_trsm_panel<double>(s, (double *)d->mat + off, d->bsizi, cnt, (const double *)lkk,
-                              (const double *)g.winv, d->mbi, 1.0);
-  else
-    launch_trsm_panel<float>(s, (float *)d->mat + off, d->bsizi, cnt, (const float *)lkk,
-                             (const float *)g.winv, d->mbi, 1.0f);
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
-static int wave_update_range(chol_desc_t *d, const void *const *panel_base, const int *panel_first,
-                             const ColRange &r, hipStream_t s) {
-  if (r.na + r.nb <= 0) return 0;
-  PanelRef pan;
-  memset(&pan, 0, sizeof pan);
-  pan.P = d->p;
-  for (int q = 0; q < d->p; ++q) {
-    pan.base[q] = panel_base[q];
-    pan.first[q] = panel_first[q];
-  }
-  const LocalMat C = local_mat(d, d->mat);
-  if (d->dtype == CHOL_REAL_DOUBLE)
-    launch_trail_update<double>(s, C, d->d_list, r.off, r.na, r.offb, r.nb, pan, true);
-  else
-    launch_trail_update<float>(s, C, d->d_list, r.off, r.na, r.offb, r.nb, pan, true);
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
-static inline bool owns_tile(const chol_desc *d, int I, int J) {
-  return I % d->p == d->prow && J % d->q == d->pcol;
-}
-
-int chol_wave_update(chol_desc_t *d, int k, int jlo, int jhi, const void *const *panel_base,
-                     const int *panel_first, int skip_diag, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update before chol_init");
-  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update: NULL");
-  if (jlo <= k) jlo = k + 1;
-  if (jhi > d->nt) jhi = d->nt;
-  if (jlo >= jhi) return 0;
-  ColRange r = col_range(d, jlo, jhi);
-  // diagonal tiles are listed by column descending: that of column jlo, when this process owns
-  // it, is the last one of the segment
-  if (skip_diag && owns_tile(d, jlo, jlo)) --r.nb;
-  return wave_update_range(d, panel_base, panel_first, r, (hipStream_t)stream);
-}
-
-int chol_wave_update_diag(chol_desc_t *d, int k, int j, const void *const *panel_base,
-                          const int *panel_first, void *stream) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "wave_update_diag before chol_init");
-  if (!d || !panel_base || !panel_first) return fail(-1, "wave_update_diag: NULL");
-  if (j <= k || j >= d->nt) return fail(-3, "wave_update_diag: j out of range");
-  if (!owns_tile(d, j, j)) return fail(-3, "wave_update_diag: this process does not own tile (j,j)");
-  if (cholmi::g_intile_small) {
-    const int pr = j % d->p;
-    const size_t aoff = (size_t)(j / d->p - panel_first[pr]) * d->bsizi, coff = ((size_t)(j / d->p) + (size_t)(j / d->q) * d->lmt) * d->bsizi;
-    if (d->dtype == CHOL_REAL_DOUBLE)
-      launch_diag_syrk<double>((hipStream_t)stream, (double *)d->mat + coff, (const double *)panel_base[pr] + aoff, d->mbi);
-    else
-      launch_diag_syrk<float>((hipStream_t)stream, (float *)d->mat + coff, (const float *)panel_base[pr] + aoff, d->mbi);
-    HIPCHECK(hipGetLastError());
-    return 0;
-  }
-  ColRange r;
-  r.off = 0;
-  r.na = 0;
-  r.offb = d->n_off + d->gd[j + 1];
-  r.nb = 1;
-  return wave_update_range(d, panel_base, panel_first, r, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -29,7 +29,63 @@ struct chol_desc {
   int n_off = 0;
 };
 
+extern "C" int chol_internal_fail(int code, const char *msg);  // api.hip: sets chol_last_error, returns code
+
 namespace cholmi {
+
+// streams of one rank's factorisation (walker.h)
+enum { ST_MAIN = 0, ST_PANEL, ST_TRSM, ST_U1, ST_CX, ST_PX, ST_COUNT };
+
+constexpr int SEM_SLOTS = 16384;   // device-side counters: 3 mb/128 + 1 per tile column ...
+constexpr int TILE_SEM_SETS = 8;   // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
+constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
+
+// device buffers that live as long as the context (receive buffers of the distributed walker)
+struct DevPool {
+  struct Blk {
+    void *p;
+    size_t bytes;
+    bool used;
+  };
+  std::vector<Blk> blks;
+  void *get(size_t bytes);
+  void release_all() {
+    for (auto &b : blks) b.used = false;
+  }
+  void free_all();
+};
+
+// Everything one rank's factorisation runs on: its streams, workspaces, counters, events, timings.  The process
+// has one (api.hip: the context behind the C ABI); the one-GPU rehearsal of the distributed walker makes more.
+struct RankCtx {
+  int device = -1;
+  hipStream_t st[ST_COUNT] = {};
+  void *winv = nullptr;  // inverses of the 128x128 diagonal blocks of L(k,k), two sets (wave parity)
+  size_t winv_bytes = 0;
+  int *d_info = nullptr;
+  int *d_sem = nullptr;  // device-side dependency counters of the panel chain (kernels.hip: sem_wait), or null
+  unsigned tile_sem_next = 0;
+  std::vector<hipEvent_t> events;
+  bool profiling = false;
+  // stats of the last whole-matrix potrf
+  double total_ms = 0, update_ms = 0, update_flops = 0, issue_us = 0;
+  int update_launches = 0;
+  long long sends = 0, recvs = 0, bytes_sent = 0;
+  DevPool pool;
+  // measured once at creation, by dtype (0 = f64, 1 = f32): the register-only MFMA stream's rate [TFLOP/s]
+  // and one 128 x 128 diagonal-block step of the panel chain alone [us]; what the walker's regime switches use
+  double probe_tflops[2] = {0, 0}, diag_us[2] = {0, 0};
+};
+int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from);  // api.hip
+void rank_ctx_destroy(RankCtx *r);
+RankCtx *main_rank_ctx();
+int main_rank(int *nranks);
+
+// The trailing update inside the DAG runs at about this fraction of the register-only MFMA stream, and one
+// 128-step of the panel chain (diagonal block, in-tile solve and update, launch gaps) takes about this many
+// times the diagonal-block kernel alone (rounds 1-2, fp64: 65 of 76.4 TFLOP/s; 130 of 49 us): the units the
+// walker's regime thresholds were tuned in, now derived from what chol_init measures per dtype.
+constexpr double CHOLMI_UPDATE_EFF = 0.85, CHOLMI_STEP_FACTOR = 2.65;
 
 constexpr int MACRO = 128;  // macro-tile edge: one workgroup's C block, and the
                             // diagonal-block size of the in-tile POTRF/TRSM

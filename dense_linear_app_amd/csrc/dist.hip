@@ -1,485 +1,262 @@
-// 2D block-cyclic tiled Cholesky over p x q processes (one per GPU) behind chol_potrf_tile:
-// the wave loop of the reference client (client_distrib.cpp:506-565) with Chameleon's descriptor
-// distribution (p, q: worker_distrib.cpp:77, v6_test.c:26-27, 44-45; always 1 x 1 in the reference).
-// Tile (I,J) lives on rank (I mod p) q + (J mod q); owner computes.  What moves per wave k
-// (SURVEY 8e), point to point, one transport group each:
-//   1. L(k,k) and the inverses of its 128-blocks: owner -> the other ranks of process column k mod q;
-//   2. the head tile L(k+1,k) alone, ahead of everything else, to the owner of (k+1,k+1): that rank
-//      applies the one SYRK, factors the next diagonal tile and ships it while the rest of panel k
-//      is still on the wire (POTRF and its send are off the per-wave critical path);
-//   3. panel k: the part of process row r (tiles i = r mod p, contiguous in its owner's storage, no
-//      packing) goes whole to the other ranks of that process row -- they need L(i,k) as the row
-//      operand of their tiles (i, j) -- and tile by tile to the ranks (r', j mod q), r' != r, which
-//      need L(j,k) as the column operand of their tiles (i, j).  Nobody receives a tile it does not
-//      use: (1/p + 1/q) of the panel per rank instead of all of it.
-// Three streams per rank, receive buffers double-buffered by wave parity, one wave of lookahead:
-//   main   U1(k) = columns k+1, k+2 by panel k; U2(k) = the columns beyond
-//   side   TRSM(k+1), head tile, exchange of panel k+1 -- while U2(k) runs
-//   early  SYRK on (k+1,k+1) from the head tile, POTRF(k+1), its sends
-// The loop is written against `Engine` (tile kernels + streams) and chol_transport_t (exchange):
-// the product engine launches the HIP kernels through the library's own wave entry points; the test
-// engine (chol_dist_factorize_with) lets the CPU suite drive the same loop with the oracle's tile
-// kernels under gloo.
+// chol_potrf_tile on a whole tiled matrix: the wave walker (walker.h) instantiated for
+//   * this process's GPU (HipOps): one GPU (p = q = 1: v6_test.c:44-56) or its share of a p x q 2D block-cyclic
+//     matrix, one process per GPU (v6_test.c:26-27 passes p, q into CHAMELEON_Desc_Create; tile (I,J) lives on
+//     rank (I mod p) q + (J mod q), owner computes);
+//   * caller-supplied tile kernels on the CPU (CbOps, chol_dist_factorize_with): the test hook that lets the
+//     CPU suite drive the same schedule -- ownership, addressing, matching of sends and receives, buffer reuse --
+//     with the oracle's kernels under gloo.  Never used by chol_potrf_tile.
+// and the transports the p x q walker moves tiles with (include/cholmi.h: chol_transport_t, two channels):
+//   * RCCL (xGMI inside a node), loaded at run time: two communicators, one per communication stream;
+//   * whatever table the application installs (the tests: torch.distributed / gloo);
+//   * an in-process asynchronous one (chol_dist_rehearse): p*q ranks as threads of this process on ONE GPU,
+//     every send / receive a stream-ordered device copy, no device synchronisation anywhere -- the real
+//     kernels, streams, events and buffer reuse of the multi-GPU schedule on the one GPU a test box has.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
 
-#include <chrono>
+#include <condition_variable>
 #include <cstdio>
-#include <cstdlib>
-#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <tuple>
 #include <vector>
+
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>  // types and enum values only: the library itself is resolved with dlopen at run time
+#define CHOLMI_RCCL_HEADER 1
+#else
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef void *ncclComm_t;
+typedef int ncclResult_t;
+enum { ncclInt8 = 0, ncclInt64 = 4 };
+enum { ncclMax = 2 };
+#define NCCL_MAJOR 2
+#define NCCL_VERSION_CODE 20700
+#endif
 
 #include "../../include/cholmi.h"
 #include "cholmi_internal.h"
+#include "walker.h"
 
-extern "C" int chol_internal_fail(int code, const char *msg);  // api.hip: sets chol_last_error
+using namespace cholmi;
+
+extern "C" int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm, int ln,
+                                         int i, int j, int m, int n, int p, int q, int rank, int nranks);  // api.hip
 
 namespace {
 
-enum { S_MAIN = 0, S_SIDE = 1, S_EARLY = 2 };
-enum { EV_HEAD0 = 0, EV_HEAD1 = 1, EV_U1 = 2, EV_DIAG = 3, EV_TMP = 4, EV_COUNT = 5 };
-
-struct Engine {
-  int N = 0, B = 0, P = 1, Q = 1, rank = 0, nt = 0, prow = 0, pcol = 0, lmt = 0, lnt = 0;
-  size_t esize = 8;
-  size_t tile_bytes = 0;
-  virtual ~Engine() {}
-  virtual char *store() = 0;
-  virtual void *alloc(size_t bytes) = 0;
-  virtual int potrf(int k, void *lkk, int s) = 0;
-  virtual size_t winv_bytes() = 0;
-  virtual int export_winv(void *dst, int s) = 0;
-  virtual int import_winv(const void *src, int s) = 0;
-  virtual int trsm(int k, const void *lkk, int s) = 0;
-  virtual int update(int k, int jlo, int jhi, const void *const *bases, const int *firsts, int skip_diag, int s) = 0;
-  virtual int update_diag(int k, int j, const void *const *bases, const int *firsts, int s) = 0;
-  virtual int copy(void *dst, const void *src, size_t bytes, int s) = 0;
-  virtual void *stream(int s) = 0;
-  virtual int record(int s, int ev) = 0;
-  virtual int wait_event(int s, int ev) = 0;
-  virtual int sync() = 0;
-  virtual int reset_info() = 0;
-  virtual int info(int *out) = 0;
-  int wait_stream(int waiter, int waited) {
-    int rc = record(waited, EV_TMP);
-    return rc ? rc : wait_event(waiter, EV_TMP);
-  }
-  char *tile_ptr(int il, int jl) { return store() + ((size_t)il + (size_t)jl * lmt) * tile_bytes; }
-  void geometry(int N_, int B_, int P_, int Q_, int rank_, size_t esize_) {
-    N = N_, B = B_, P = P_, Q = Q_, rank = rank_, esize = esize_;
-    nt = (N + B - 1) / B;
-    prow = rank / Q, pcol = rank % Q;
-    lmt = nt - prow > 0 ? (nt - prow + P - 1) / P : 0;
-    lnt = nt - pcol > 0 ? (nt - pcol + Q - 1) / Q : 0;
-    tile_bytes = (size_t)B * B * esize;
-  }
-};
-
-#define RC(call)        \
-  do {                  \
-    int rc_ = (call);   \
-    if (rc_) return rc_; \
+int hip_fail(hipError_t e, const char *what) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s failed (walker): %s", what, hipGetErrorString(e));
+  return chol_internal_fail(CHOL_ERR_HIP, buf);
+}
+#define HIPRC(call)                                      \
+  do {                                                   \
+    hipError_t e_ = (call);                              \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);    \
   } while (0)
 
-struct Dist {
-  Engine &e;
-  chol_transport_t tr;
-  bool have_tr;
-  char *lkk_buf[2] = {nullptr, nullptr}, *head_buf[2] = {nullptr, nullptr};
-  std::vector<char *> pbuf[2];
-  const void *lkk_ptr[2] = {nullptr, nullptr};
-  size_t nw = 0;
-  long long nsend = 0, nrecv = 0, bytes_sent = 0;
-  bool in_group = false;
-
-  Dist(Engine &eng, const chol_transport_t *t) : e(eng), have_tr(t != nullptr) {
-    if (t) tr = *t;
-  }
-  int rank_of(int pr, int pc) const { return pr * e.Q + pc; }
-  int fla(int k, int p2) const { return (k + e.P - p2) / e.P; }  // first local row with global index > k
-  void part(int k, int p2, int *il0, int *cnt) const {
-    *il0 = fla(k, p2);
-    const int rows = e.nt - p2 > 0 ? (e.nt - p2 + e.P - 1) / e.P : 0;
-    *cnt = rows - *il0 > 0 ? rows - *il0 : 0;
-  }
-  int begin() {
-    if (!in_group) {
-      in_group = true;
-      return tr.group_begin(tr.ctx);
-    }
-    return 0;
-  }
-  int end() {
-    if (in_group) {
-      in_group = false;
-      return tr.group_end(tr.ctx);
-    }
-    return 0;
-  }
-  int send(const void *buf, size_t bytes, int peer, int s) {
-    RC(begin());
-    ++nsend;
-    bytes_sent += (long long)bytes;
-    return tr.send(tr.ctx, buf, bytes, peer, e.stream(s));
-  }
-  int recv(void *buf, size_t bytes, int peer, int s) {
-    RC(begin());
-    ++nrecv;
-    return tr.recv(tr.ctx, buf, bytes, peer, e.stream(s));
-  }
-
-  int setup() {
-    const int world = e.P * e.Q;
-    if (world > 1 && !have_tr) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: no transport installed (chol_set_transport / chol_transport_rccl_init)");
-    nw = e.winv_bytes();
-    const int maxpart = (e.nt + e.P - 1) / e.P;
-    for (int par = 0; par < 2; ++par) {
-      lkk_buf[par] = (char *)e.alloc(e.tile_bytes + nw);
-      head_buf[par] = (char *)e.alloc(e.tile_bytes);
-      pbuf[par].assign(e.P, nullptr);
-      for (int p2 = 0; p2 < e.P; ++p2) pbuf[par][p2] = (char *)e.alloc((size_t)(maxpart > 0 ? maxpart : 1) * e.tile_bytes);
-      if (!lkk_buf[par] || !head_buf[par]) return chol_internal_fail(CHOL_ERR_OUT_OF_MEMORY, "distributed potrf: buffer allocation failed");
-      for (char *p : pbuf[par])
-        if (!p) return chol_internal_fail(CHOL_ERR_OUT_OF_MEMORY, "distributed potrf: buffer allocation failed");
-    }
-    return 0;
-  }
-
-  // L(k,k): POTRF on its owner, then (with its block inverses) to the other ranks of the process column
-  int diag(int k, int s) {
-    const int pr = k % e.P, pc = k % e.Q, par = k & 1;
-    if (e.pcol != pc) return 0;
-    const bool last = k + 1 >= e.nt;
-    char *buf = lkk_buf[par];
-    if (e.prow == pr) {
-      char *lkk = e.tile_ptr(k / e.P, k / e.Q);
-      RC(e.potrf(k, lkk, s));
-      if (e.P > 1 && !last) {
-        RC(e.copy(buf, lkk, e.tile_bytes, s));
-        if (nw) RC(e.export_winv(buf + e.tile_bytes, s));
-        for (int r2 = 0; r2 < e.P; ++r2)
-          if (r2 != pr) RC(send(buf, e.tile_bytes + nw, rank_of(r2, pc), s));
-        RC(end());
-      }
-      lkk_ptr[par] = lkk;
-    } else {
-      if (e.P > 1 && !last) {
-        RC(recv(buf, e.tile_bytes + nw, rank_of(pr, pc), s));
-        RC(end());
-        if (nw) RC(e.import_winv(buf + e.tile_bytes, s));
-      }
-      lkk_ptr[par] = buf;
-    }
-    return 0;
-  }
-
-  // TRSM of the local tiles of panel k, then its head tile L(k+1,k) to the owner of (k+1,k+1)
-  int trsm_and_head(int k, int s, bool send_head, const void **head) {
-    const int pc = k % e.Q, par = k & 1;
-    *head = nullptr;
-    if (e.pcol == pc) RC(e.trsm(k, lkk_ptr[par], s));
-    if (!send_head || k + 1 >= e.nt) return 0;
-    const int h = rank_of((k + 1) % e.P, pc), d1 = rank_of((k + 1) % e.P, (k + 1) % e.Q);
-    if (e.rank == h) {
-      char *t = e.tile_ptr((k + 1) / e.P, k / e.Q);
-      if (d1 != h) {
-        RC(send(t, e.tile_bytes, d1, s));
-        RC(end());
-      } else {
-        *head = t;
-      }
-    } else if (e.rank == d1) {
-      RC(recv(head_buf[par], e.tile_bytes, h, s));
-      RC(end());
-      *head = head_buf[par];
-    }
-    return e.record(s, EV_HEAD0 + par);
-  }
-
-  // panel k to everybody who uses it; -> where tile i of the panel is on this rank (bases / firsts)
-  int exchange(int k, int s, const void **bases, int *firsts) {
-    const int pc = k % e.Q, par = k & 1;
-    for (int p2 = 0; p2 < e.P; ++p2) {
-      int il0, cnt;
-      part(k, p2, &il0, &cnt);
-      firsts[p2] = il0;
-      if (e.prow == p2 && e.pcol == pc) {
-        char *src = cnt > 0 ? e.tile_ptr(il0, k / e.Q) : pbuf[par][p2];
-        bases[p2] = src;
-        if (cnt <= 0) continue;
-        for (int c2 = 0; c2 < e.Q; ++c2)  // along the process row: the whole part
-          if (c2 != pc) RC(send(src, (size_t)cnt * e.tile_bytes, rank_of(p2, c2), s));
-        for (int r2 = 0; r2 < e.P; ++r2) {  // to the other process rows: tile j to process column j mod q
-          if (r2 == p2) continue;
-          for (int t = 0; t < cnt; ++t) {
-            const int j = (il0 + t) * e.P + p2;
-            RC(send(src + (size_t)t * e.tile_bytes, e.tile_bytes, rank_of(r2, j % e.Q), s));
-          }
-        }
-      } else {
-        char *buf = pbuf[par][p2];
-        bases[p2] = buf;
-        if (cnt <= 0) continue;
-        if (e.prow == p2) {
-          RC(recv(buf, (size_t)cnt * e.tile_bytes, rank_of(p2, pc), s));
-        } else {
-          for (int t = 0; t < cnt; ++t) {
-            const int j = (il0 + t) * e.P + p2;
-            if (j % e.Q == e.pcol) RC(recv(buf + (size_t)t * e.tile_bytes, e.tile_bytes, rank_of(p2, pc), s));
-          }
-        }
-      }
-    }
-    return end();
-  }
-
-  struct Panel {
-    std::vector<const void *> bases;
-    std::vector<int> firsts;
-    const void *head = nullptr;
-  };
-  int panel(int k, int s, bool send_head, Panel *p) {
-    p->bases.assign(e.P, nullptr);
-    p->firsts.assign(e.P, 0);
-    RC(trsm_and_head(k, s, send_head, &p->head));
-    return exchange(k, s, p->bases.data(), p->firsts.data());
-  }
-
-  double issue_us = 0;
-  int factorize(bool lookahead, long long *info_out) {
-    const auto t0 = std::chrono::steady_clock::now();
-    const int nt = e.nt, P = e.P, Q = e.Q;
-    RC(e.reset_info());
-    if (!lookahead) {
-      // the plain wave order on one stream (C2:506-565)
-      for (int k = 0; k < nt; ++k) {
-        RC(diag(k, S_MAIN));
-        if (k + 1 < nt) {
-          Panel p;
-          RC(panel(k, S_MAIN, false, &p));
-          RC(e.update(k, k + 1, nt, p.bases.data(), p.firsts.data(), 0, S_MAIN));
-        }
-      }
-    } else {
-      RC(e.wait_stream(S_SIDE, S_MAIN));
-      RC(e.wait_stream(S_EARLY, S_MAIN));
-      RC(diag(0, S_EARLY));
-      RC(e.wait_stream(S_SIDE, S_EARLY));
-      Panel cur, nxt;
-      if (nt > 1) RC(panel(0, S_SIDE, true, &cur));
-      bool have_u1 = false;
-      for (int k = 0; k + 1 < nt; ++k) {
-        // early: the diagonal tile of the next wave, as soon as the head tile L(k+1,k) is in
-        RC(e.wait_event(S_EARLY, EV_HEAD0 + (k & 1)));
-        if (have_u1) RC(e.wait_event(S_EARLY, EV_U1));  // (k+1,k+1) carries every update up to wave k-1
-        if (rank_of((k + 1) % P, (k + 1) % Q) == e.rank) {
-          std::vector<const void *> hb(P, cur.head);
-          std::vector<int> hf(P, 0);
-          hf[(k + 1) % P] = (k + 1) / P;
-          RC(e.update_diag(k, k + 1, hb.data(), hf.data(), S_EARLY));
-        }
-        RC(diag(k + 1, S_EARLY));
-        RC(e.record(S_EARLY, EV_DIAG));
-        // main: panel k complete (and received); columns k+1 and k+2 first
-        RC(e.wait_stream(S_MAIN, S_SIDE));
-        RC(e.update(k, k + 1, k + 3, cur.bases.data(), cur.firsts.data(), 1, S_MAIN));
-        RC(e.record(S_MAIN, EV_U1));
-        have_u1 = true;
-        if (k + 2 < nt) {
-          RC(e.wait_event(S_SIDE, EV_U1));
-          RC(e.wait_event(S_SIDE, EV_DIAG));
-          RC(panel(k + 1, S_SIDE, true, &nxt));
-        }
-        RC(e.update(k, k + 3, nt, cur.bases.data(), cur.firsts.data(), 0, S_MAIN));
-        std::swap(cur, nxt);
-      }
-      RC(e.wait_stream(S_MAIN, S_SIDE));
-      RC(e.wait_stream(S_MAIN, S_EARLY));
-    }
-    issue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    RC(e.sync());
-    int info = 0;
-    RC(e.info(&info));
-    // the smallest positive info wins: MAX-reduce (2^40 - info), 0 = success
-    long long v = info > 0 ? (1LL << 40) - info : 0;
-    if (P * Q > 1) RC(tr.allreduce_max(tr.ctx, &v));
-    *info_out = v == 0 ? 0 : (1LL << 40) - v;
-    return 0;
-  }
+struct ColRange {
+  int off, na, offb, nb;
 };
-
-// ---------------------------------------------------------------- product engine: HIP kernels
-struct Pool {
-  struct Blk {
-    void *p;
-    size_t bytes;
-    bool used;
-  };
-  std::vector<Blk> blks;
-  void *get(size_t bytes) {
-    for (auto &b : blks)
-      if (!b.used && b.bytes >= bytes) {
-        b.used = true;
-        return b.p;
-      }
-    void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    blks.push_back({p, bytes, true});
-    return p;
-  }
-  void release_all() {
-    for (auto &b : blks) b.used = false;
-  }
-  void free_all() {
-    for (auto &b : blks) (void)hipFree(b.p);
-    blks.clear();
-  }
-};
-Pool g_pool;
-hipStream_t g_streams[3] = {nullptr, nullptr, nullptr};
-hipEvent_t g_events[EV_COUNT];
-bool g_hip_ready = false;
-
-int hip_ready() {
-  if (g_hip_ready) return 0;
-  int lo = 0, hi = 0;
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return chol_internal_fail(CHOL_ERR_HIP, "stream priority range");
-  // CHOLMI_COMM_CUS = n: the update stream leaves n CUs of every XCD-pair alone, so that the transport's
-  // kernels (RCCL) always find a free CU; they cannot raise the yield table themselves.  Off by default:
-  // any mask costs the update more than it buys on one GPU.
-  const char *cm = getenv("CHOLMI_COMM_CUS");
-  const int reserve = cm ? atoi(cm) : 0;
-  hipError_t e = hipSuccess;
-  if (reserve > 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    e = hipGetDeviceProperties(&prop, dev);
-    const int ncu = e == hipSuccess ? prop.multiProcessorCount : 256;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
-    for (int c = 0; c < reserve && c < ncu; ++c) {
-      const int cu = (int)((long)c * ncu / reserve);  // spread over the chip
-      mask[cu / 32] &= ~(1u << (cu % 32));
-    }
-    e = hipExtStreamCreateWithCUMask(&g_streams[S_MAIN], (uint32_t)mask.size(), mask.data());
-  } else {
-    e = hipStreamCreateWithPriority(&g_streams[S_MAIN], hipStreamNonBlocking, lo);
-  }
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&g_streams[S_SIDE], hipStreamNonBlocking, hi);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&g_streams[S_EARLY], hipStreamNonBlocking, hi);
-  for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming);
-  if (e != hipSuccess) return chol_internal_fail(CHOL_ERR_HIP, hipGetErrorString(e));
-  g_hip_ready = true;
-  return 0;
+inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
+  jlo = std::min(jlo, d->nt), jhi = std::min(jhi, d->nt);
+  ColRange r;
+  r.off = d->ge[jhi];
+  r.na = d->ge[jlo] - d->ge[jhi];
+  r.offb = d->n_off + d->gd[jhi];
+  r.nb = d->gd[jlo] - d->gd[jhi];
+  return r;
 }
 
-struct HipEngine : Engine {
+// ---------------------------------------------------------------- product ops: HIP kernels and streams
+template <typename T>
+struct HipOps {
+  RankCtx &r;
   chol_desc *d;
-  explicit HipEngine(chol_desc *desc, int rank_) : d(desc) {
-    geometry(desc->lm, desc->mbi, desc->p, desc->q, rank_, desc->esize);
+  char *base;
+  const WaveGeo &g;
+  bool reset_ytab;
+  bool sem_ok = false;
+  LocalMat C;
+  HipOps(RankCtx &rc, chol_desc *desc, void *b, const WaveGeo &geo, bool ry) : r(rc), d(desc), base((char *)b), g(geo), reset_ytab(ry) {
+    C.base = b;
+    C.lmt = desc->lmt;
+    C.P = desc->p;
+    C.Q = desc->q;
+    C.mb = desc->mbi;
+    C.bsiz = desc->bsizi;
   }
-  char *store() override { return (char *)d->mat; }
-  void *alloc(size_t bytes) override { return g_pool.get(bytes); }
-  int potrf(int k, void *lkk, int s) override { return chol_wave_potrf(d, k, lkk, g_streams[s]); }
-  size_t winv_bytes() override { return chol_wave_winv_bytes(d); }
-  int export_winv(void *dst, int s) override { return chol_wave_export_winv(d, dst, g_streams[s]); }
-  int import_winv(const void *src, int s) override { return chol_wave_import_winv(d, src, g_streams[s]); }
-  int trsm(int k, const void *lkk, int s) override { return chol_wave_trsm(d, k, lkk, g_streams[s]); }
-  int update(int k, int jlo, int jhi, const void *const *bases, const int *firsts, int skip_diag, int s) override {
-    return chol_wave_update(d, k, jlo, jhi, bases, firsts, skip_diag, g_streams[s]);
+  bool profiling() const { return r.profiling; }
+  bool pipe_ok() const { return g_intile_small && g_trsm_fused_min <= 0; }
+  bool counters() const { return sem_ok; }
+  bool can_split_trsm() const { return true; }
+  void *stream(int st) { return r.st[st]; }
+  char *tile(int il, int jl) { return base + ((size_t)il + (size_t)jl * g.lmt) * g.tile_bytes; }
+  void *winv(int par) { return (char *)r.winv + (size_t)par * r.winv_bytes; }
+  void *alloc(size_t bytes) { return r.pool.get(bytes); }
+  int *sem(int k, int which, int per_wave) { return r.d_sem + ((size_t)per_wave * k + which) * 32; }
+  int launched() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
   }
-  int update_diag(int k, int j, const void *const *bases, const int *firsts, int s) override {
-    return chol_wave_update_diag(d, k, j, bases, firsts, g_streams[s]);
-  }
-  int copy(void *dst, const void *src, size_t bytes, int s) override {
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_streams[s]) == hipSuccess
-               ? 0
-               : chol_internal_fail(CHOL_ERR_HIP, "hipMemcpyAsync (distributed potrf)");
-  }
-  void *stream(int s) override { return g_streams[s]; }
-  int record(int s, int ev) override {
-    return hipEventRecord(g_events[ev], g_streams[s]) == hipSuccess ? 0 : chol_internal_fail(CHOL_ERR_HIP, "hipEventRecord");
-  }
-  int wait_event(int s, int ev) override {
-    return hipStreamWaitEvent(g_streams[s], g_events[ev], 0) == hipSuccess ? 0 : chol_internal_fail(CHOL_ERR_HIP, "hipStreamWaitEvent");
-  }
-  int sync() override {
-    for (int s = 0; s < 3; ++s)
-      if (hipStreamSynchronize(g_streams[s]) != hipSuccess) return chol_internal_fail(CHOL_ERR_HIP, "hipStreamSynchronize (distributed potrf)");
+  int begin(int nevents, int nt, int sem_per_wave) {
+    while ((int)r.events.size() < nevents) {
+      hipEvent_t e;
+      HIPRC(hipEventCreate(&e));
+      r.events.push_back(e);
+    }
+    HIPRC(hipMemsetAsync(r.d_info, 0, sizeof(int), r.st[ST_MAIN]));
+    if (g_ytab && reset_ytab) HIPRC(hipMemsetAsync(g_ytab, 0, YTAB_ENTRIES * sizeof(int), r.st[ST_MAIN]));
+    // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): 3 nbm + 1
+    // counters per wave, the last one = workgroups of the last SYRK slice on tile (k+1,k+1)
+    sem_ok = r.d_sem && g.P * g.Q == 1 && (long)nt * sem_per_wave <= SEM_SLOTS;
+    if (sem_ok) HIPRC(hipMemsetAsync(r.d_sem, 0, (size_t)nt * sem_per_wave * 32 * sizeof(int), r.st[ST_MAIN]));
     return 0;
   }
-  int reset_info() override { return chol_reset_info(); }
-  int info(int *out) override { return chol_get_info(out); }
+  int rec(int ev, int st) {
+    HIPRC(hipEventRecord(r.events[ev], r.st[st]));
+    return 0;
+  }
+  int wt(int st, int ev) {
+    HIPRC(hipStreamWaitEvent(r.st[st], r.events[ev], 0));
+    return 0;
+  }
+  int panel(int k, char *lkk, void *wv, char *tiles, int ntiles, int ev_steps, int ev_head, const SyrkPipe *sy,
+            const int *wait_sem, int wait_target) {
+    launch_panel_pipelined<T>(r.st[ST_PANEL], r.st[ST_TRSM], &r.events[ev_steps], (T *)lkk, g.mb, (T *)wv, r.d_info,
+                              k * g.mb, (T *)tiles, (long)g.mb * g.mb, ntiles, ev_head >= 0 ? r.events[ev_head] : nullptr,
+                              false, nullptr, sy, wait_sem, wait_target);
+    return launched();
+  }
+  int trsm(int, char *tiles, int ntiles, const char *lkk, const char *wv, int st) {
+    launch_trsm_panel<T>(r.st[st], (T *)tiles, (long)g.mb * g.mb, ntiles, (const T *)lkk, (const T *)wv, g.mb, T(1));
+    return launched();
+  }
+  int diag_syrk(int, int, char *Cjj, const char *A, int st) {
+    launch_diag_syrk<T>(r.st[st], (T *)Cjj, (const T *)A, g.mb);
+    return launched();
+  }
+  int update(int, int, int jlo, int jhi, int what, const PanelRef &p1, const PanelRef *p2, bool yield, int st) {
+    const ColRange c = col_range(d, jlo, jhi);
+    launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2);
+    return launched();
+  }
+  // the streams have been joined into ST_MAIN and `ev_stop` recorded there
+  int finish(int ev_start, int ev_stop, const std::vector<std::pair<int, int>> &brackets, int *info) {
+    HIPRC(hipStreamSynchronize(r.st[ST_MAIN]));
+    float ms = 0;
+    HIPRC(hipEventElapsedTime(&ms, r.events[ev_start], r.events[ev_stop]));
+    r.total_ms = ms;
+    r.update_ms = 0;
+    if (r.profiling) {
+      // union of the brackets (disjoint by construction except around the waves launched as halves)
+      std::vector<std::pair<float, float>> iv;
+      for (auto &b : brackets) {
+        float t0 = 0, t1 = 0;
+        if (hipEventElapsedTime(&t0, r.events[ev_start], r.events[b.first]) != hipSuccess ||
+            hipEventElapsedTime(&t1, r.events[ev_start], r.events[b.second]) != hipSuccess) {
+          (void)hipGetLastError();  // a bracket of a wave that launched nothing on this rank
+          continue;
+        }
+        if (t1 > t0) iv.emplace_back(t0, t1);
+      }
+      std::sort(iv.begin(), iv.end());
+      float hi = -1;
+      for (auto &p : iv) {
+        if (p.first > hi) r.update_ms += p.second - p.first;
+        else if (p.second > hi) r.update_ms += p.second - hi;
+        hi = std::max(hi, p.second);
+      }
+    }
+    HIPRC(hipMemcpy(info, r.d_info, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+  }
 };
 
-// ---------------------------------------------------------------- test engine: callbacks, no streams
-struct CbEngine : Engine {
+// ---------------------------------------------------------------- test ops: callbacks, executed in issue order
+struct CbOps {
   chol_test_engine_t cb;
-  std::vector<void *> owned;
-  CbEngine(const chol_test_engine_t &c, int N_, int B_, int P_, int Q_, int rank_) : cb(c) {
-    geometry(N_, B_, P_, Q_, rank_, c.esize);
+  const WaveGeo &g;
+  CbOps(const chol_test_engine_t &c, const WaveGeo &geo) : cb(c), g(geo) {}
+  bool profiling() const { return false; }
+  bool pipe_ok() const { return false; }
+  bool counters() const { return false; }
+  bool can_split_trsm() const { return false; }  // the engine's trsm callback solves all local tiles of a panel
+  void *stream(int) { return nullptr; }
+  char *tile(int il, int jl) { return (char *)cb.store + ((size_t)il + (size_t)jl * g.lmt) * g.tile_bytes; }
+  void *winv(int) { return nullptr; }
+  void *alloc(size_t bytes) { return cb.alloc(cb.ctx, bytes); }
+  int *sem(int, int, int) { return nullptr; }
+  int begin(int, int, int) { return 0; }
+  int rec(int, int) { return 0; }
+  int wt(int, int) { return 0; }
+  int panel(int k, char *lkk, void *, char *, int ntiles, int, int, const SyrkPipe *, const int *, int) {
+    WRC(cb.potrf(cb.ctx, k, lkk));
+    return ntiles > 0 ? cb.trsm(cb.ctx, k, lkk) : 0;
   }
-  char *store() override { return (char *)cb.store; }
-  void *alloc(size_t bytes) override { return cb.alloc(cb.ctx, bytes); }
-  int potrf(int k, void *lkk, int) override { return cb.potrf(cb.ctx, k, lkk); }
-  size_t winv_bytes() override { return 0; }
-  int export_winv(void *, int) override { return 0; }
-  int import_winv(const void *, int) override { return 0; }
-  int trsm(int k, const void *lkk, int) override { return cb.trsm(cb.ctx, k, lkk); }
-  int update(int k, int jlo, int jhi, const void *const *bases, const int *firsts, int skip_diag, int) override {
-    return cb.update(cb.ctx, k, jlo, jhi, bases, firsts, skip_diag);
+  int trsm(int k, char *, int, const char *lkk, const char *, int) { return cb.trsm(cb.ctx, k, lkk); }
+  int diag_syrk(int k, int j, char *, const char *A, int) {
+    std::vector<const void *> hb(g.P, A);
+    std::vector<int> hf(g.P, 0);
+    hf[j % g.P] = j / g.P;
+    return cb.update_diag(cb.ctx, k, j, hb.data(), hf.data());
   }
-  int update_diag(int k, int j, const void *const *bases, const int *firsts, int) override {
-    return cb.update_diag(cb.ctx, k, j, bases, firsts);
-  }
-  int copy(void *dst, const void *src, size_t bytes, int) override {
-    memcpy(dst, src, bytes);
+  int update(int k1, int k2, int jlo, int jhi, int what, const PanelRef &p1, const PanelRef *p2, bool, int) {
+    const PanelRef *ps[2] = {&p1, p2};
+    const int ks[2] = {k1, k2};
+    for (int t = 0; t < 2; ++t) {
+      if (!ps[t] || ks[t] < 0) continue;
+      if (what == 3) {
+        WRC(cb.update(cb.ctx, ks[t], jlo, jhi, ps[t]->base, ps[t]->first, 0));
+      } else if (what == 1) {
+        if (jhi != jlo + 1) return chol_internal_fail(-1, "CbOps: off-diagonal-only update of more than one column");
+        WRC(cb.update(cb.ctx, ks[t], jlo, jhi, ps[t]->base, ps[t]->first, 1));
+      } else if (what == 2) {
+        for (int j = jlo; j < std::min(jhi, g.nt); ++j)
+          if (j % g.P == g.pr && j % g.Q == g.pc) WRC(cb.update_diag(cb.ctx, ks[t], j, ps[t]->base, ps[t]->first));
+      }
+    }
     return 0;
   }
-  void *stream(int) override { return nullptr; }
-  int record(int, int) override { return 0; }
-  int wait_event(int, int) override { return 0; }
-  int sync() override { return 0; }
-  int reset_info() override { return 0; }
-  int info(int *out) override {
-    *out = cb.info(cb.ctx);
+  int finish(int, int, const std::vector<std::pair<int, int>> &, int *info) {
+    *info = cb.info(cb.ctx);
     return 0;
   }
 };
 
-// ---------------------------------------------------------------- the installed transport
-chol_transport_t g_tr;
+// ---------------------------------------------------------------- the installed transport (two channels)
+chol_transport_t g_tr[2];
 bool g_tr_set = false;
-double g_last_issue_us_per_wave = 0;
-long long g_last_sends = 0, g_last_recvs = 0, g_last_bytes = 0;
 
 // ---------------------------------------------------------------- RCCL transport (loaded on demand)
-typedef struct {
-  char internal[128];
-} nccl_uid_t;
 struct Rccl {
   void *lib = nullptr;
-  void *comm = nullptr;
-  int (*GetUniqueId)(nccl_uid_t *) = nullptr;
-  int (*CommInitRank)(void **, int, nccl_uid_t, int) = nullptr;
-  int (*CommDestroy)(void *) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
+  ncclComm_t comm[2] = {nullptr, nullptr};
+  int which[2] = {0, 1};
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, decltype(ncclInt8), int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, decltype(ncclInt8), int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, decltype(ncclInt8), decltype(ncclMax), ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
   long long *d_red = nullptr;
+  int version = 0;
 } g_rccl;
 
 int rccl_fail(const char *what, int rc) {
   char buf[256];
-  snprintf(buf, sizeof buf, "RCCL %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+  snprintf(buf, sizeof buf, "RCCL %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString((ncclResult_t)rc) : "?");
   return chol_internal_fail(CHOL_ERR_HIP, buf);
 }
 int rccl_load() {
@@ -496,6 +273,7 @@ int rccl_load() {
 #define SYM(field, name)                                                  \
   *(void **)(&g_rccl.field) = dlsym(g_rccl.lib, name);                    \
   if (!g_rccl.field) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "librccl.so lacks " name)
+  SYM(GetVersion, "ncclGetVersion");
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
@@ -506,6 +284,18 @@ int rccl_load() {
   SYM(AllReduce, "ncclAllReduce");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  // the prototypes and enum values above are those of the header this file was compiled against: the
+  // library found at run time must speak the same major version and know point-to-point operations (2.7+)
+  int v = 0;
+  const int rc = g_rccl.GetVersion(&v);
+  if (rc) return rccl_fail("ncclGetVersion", rc);
+  g_rccl.version = v;
+  const int major = v >= 10000 ? v / 10000 : v / 1000;
+  if (major != NCCL_MAJOR || v < 2700) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "librccl.so reports version code %d; this build needs major version %d with ncclSend/ncclRecv (>= 2.7)", v, NCCL_MAJOR);
+    return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, buf);
+  }
   return 0;
 }
 int rccl_group_begin(void *) {
@@ -516,29 +306,224 @@ int rccl_group_end(void *) {
   const int rc = g_rccl.GroupEnd();
   return rc ? rccl_fail("ncclGroupEnd", rc) : 0;
 }
-int rccl_send(void *, const void *buf, size_t bytes, int peer, void *stream) {
-  const int rc = g_rccl.Send(buf, bytes, /*ncclInt8*/ 0, peer, g_rccl.comm, (hipStream_t)stream);
+int rccl_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream) {
+  const int rc = g_rccl.Send(buf, bytes, ncclInt8, peer, g_rccl.comm[*(int *)ctx], (hipStream_t)stream);
   return rc ? rccl_fail("ncclSend", rc) : 0;
 }
-int rccl_recv(void *, void *buf, size_t bytes, int peer, void *stream) {
-  const int rc = g_rccl.Recv(buf, bytes, /*ncclInt8*/ 0, peer, g_rccl.comm, (hipStream_t)stream);
+int rccl_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream) {
+  const int rc = g_rccl.Recv(buf, bytes, ncclInt8, peer, g_rccl.comm[*(int *)ctx], (hipStream_t)stream);
   return rc ? rccl_fail("ncclRecv", rc) : 0;
 }
-int rccl_allreduce_max(void *, long long *value) {
+int rccl_allreduce_max(void *ctx, long long *value) {
   if (!g_rccl.d_red && hipMalloc(&g_rccl.d_red, sizeof(long long)) != hipSuccess)
     return chol_internal_fail(CHOL_ERR_OUT_OF_MEMORY, "RCCL reduction word");
-  if (hipMemcpy(g_rccl.d_red, value, sizeof(long long), hipMemcpyHostToDevice) != hipSuccess)
+  hipStream_t s = main_rank_ctx()->st[ST_MAIN];
+  if (hipMemcpyAsync(g_rccl.d_red, value, sizeof(long long), hipMemcpyHostToDevice, s) != hipSuccess)
     return chol_internal_fail(CHOL_ERR_HIP, "RCCL reduction word upload");
-  const int rc = g_rccl.AllReduce(g_rccl.d_red, g_rccl.d_red, 1, /*ncclInt64*/ 4, /*ncclMax*/ 2, g_rccl.comm, nullptr);
+  const int rc = g_rccl.AllReduce(g_rccl.d_red, g_rccl.d_red, 1, ncclInt64, ncclMax, g_rccl.comm[*(int *)ctx], s);
   if (rc) return rccl_fail("ncclAllReduce", rc);
-  if (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(value, g_rccl.d_red, sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpyAsync(value, g_rccl.d_red, sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
     return chol_internal_fail(CHOL_ERR_HIP, "RCCL reduction word download");
   return 0;
+}
+
+// ---------------------------------------------------------------- in-process asynchronous transport
+// p*q ranks as threads of one process on one GPU (chol_dist_rehearse).  send = a stream-ordered copy into a
+// staging block + an event, posted to the (channel, source, destination) mailbox; recv = wait (on the HOST,
+// for the post only) for the matching mail, make the stream wait for its event, copy out stream-ordered.
+// Exactly the ordering guarantees of ncclSend / ncclRecv on a stream, and nothing more: no device
+// synchronisation, so a buffer reused too early or an event edge missing in the walker shows up as wrong data.
+struct Hub {
+  struct Mail {
+    void *staging;
+    size_t bytes;
+    hipEvent_t ev;
+  };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<std::tuple<int, int, int>, std::deque<Mail>> box;
+  std::vector<void *> blocks;
+  std::vector<hipEvent_t> events;
+  char *arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  int nranks = 1, arrived = 0, generation = 0;
+  long long red = 0;
+  bool failed = false;
+  void *take(size_t bytes) {  // (mu held)
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (arena && arena_used + need <= arena_bytes) {
+      void *p = arena + arena_used;
+      arena_used += need;
+      return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return nullptr;
+    blocks.push_back(p);
+    return p;
+  }
+  void release() {
+    for (void *p : blocks) (void)hipFree(p);
+    blocks.clear();
+    for (auto e : events) (void)hipEventDestroy(e);
+    events.clear();
+    if (arena) (void)hipFree(arena);
+    arena = nullptr;
+  }
+};
+struct HubEnd {
+  Hub *hub;
+  int rank, ch;
+};
+int hub_group(void *) { return 0; }
+int hub_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream) {
+  HubEnd *e = (HubEnd *)ctx;
+  Hub::Mail m;
+  m.bytes = bytes;
+  {
+    std::lock_guard<std::mutex> lk(e->hub->mu);
+    m.staging = e->hub->take(bytes);
+  }
+  if (!m.staging) return chol_internal_fail(CHOL_ERR_OUT_OF_MEMORY, "rehearsal transport: staging");
+  HIPRC(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+  HIPRC(hipMemcpyAsync(m.staging, buf, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIPRC(hipEventRecord(m.ev, (hipStream_t)stream));
+  {
+    std::lock_guard<std::mutex> lk(e->hub->mu);
+    e->hub->events.push_back(m.ev);
+    e->hub->box[std::make_tuple(e->ch, e->rank, peer)].push_back(m);
+  }
+  e->hub->cv.notify_all();
+  return 0;
+}
+int hub_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream) {
+  HubEnd *e = (HubEnd *)ctx;
+  Hub::Mail m;
+  {
+    std::unique_lock<std::mutex> lk(e->hub->mu);
+    auto &q = e->hub->box[std::make_tuple(e->ch, peer, e->rank)];
+    if (!e->hub->cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty() || e->hub->failed; }) || q.empty()) {
+      e->hub->failed = true;
+      lk.unlock();
+      e->hub->cv.notify_all();
+      return chol_internal_fail(CHOL_ERR_HIP, "rehearsal transport: a receive was never matched by a send");
+    }
+    m = q.front();
+    q.pop_front();
+  }
+  if (m.bytes != bytes) return chol_internal_fail(CHOL_ERR_HIP, "rehearsal transport: send / receive sizes differ");
+  HIPRC(hipStreamWaitEvent((hipStream_t)stream, m.ev, 0));
+  HIPRC(hipMemcpyAsync(buf, m.staging, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+int hub_allreduce_max(void *ctx, long long *value) {
+  HubEnd *e = (HubEnd *)ctx;
+  Hub *h = e->hub;
+  std::unique_lock<std::mutex> lk(h->mu);
+  const int gen = h->generation;
+  if (h->arrived == 0) h->red = *value;
+  h->red = std::max(h->red, *value);
+  if (++h->arrived == h->nranks) {
+    h->arrived = 0;
+    ++h->generation;
+    lk.unlock();
+    h->cv.notify_all();
+    lk.lock();
+  } else if (!h->cv.wait_for(lk, std::chrono::seconds(300), [&] { return h->generation != gen || h->failed; }) || h->failed) {
+    h->failed = true;
+    return chol_internal_fail(CHOL_ERR_HIP, "rehearsal transport: reduction never completed");
+  }
+  *value = h->red;
+  return 0;
+}
+
+// ---------------------------------------------------------------- running the walker
+WaveCalib calib_for(const RankCtx *r, int dtype, const WaveGeo &g) {
+  const int idx = dtype == CHOL_REAL_DOUBLE ? 0 : 1;
+  WaveCalib c;
+  const double b3 = (double)g.mb * g.mb * g.mb;
+  const double rate = std::max(1.0, r->probe_tflops[idx]) * 1e12 * CHOLMI_UPDATE_EFF;
+  c.t_tile = 2.0 * b3 / rate;
+  c.t_panel = g.nbm * std::max(1.0, r->diag_us[idx]) * 1e-6 * CHOLMI_STEP_FACTOR * 1.5;
+  return c;
+}
+
+template <typename T>
+int walk_t(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool reset_ytab) {
+  WaveGeo g;
+  g.init(d->nt, d->mbi, d->p, d->q, rank, d->esize);
+  if (g.lmt != d->lmt || g.ge[0] != d->ge[0] || g.gd[0] != d->gd[0])
+    return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: descriptor does not belong to this rank");
+  HipOps<T> ops(*r, d, base, g, reset_ytab);
+  Walker<HipOps<T>> w(ops, g, cm, calib_for(r, d->dtype, g));
+  long long info = 0;
+  int rc = w.setup();
+  if (!rc) rc = w.run(&info);
+  if (rc) {
+    // leave nothing half-open behind a failure: close the transport groups, let kernels that poll a counter go
+    // (every counter raised past any target), drain the streams
+    if (cm) (void)cm->end(0), (void)cm->end(1);
+    if (ops.sem_ok) (void)hipMemsetD32Async((hipDeviceptr_t)r->d_sem, 0x3fffffff, (size_t)SEM_SLOTS * 32, r->st[ST_CX]);
+    for (int s = 0; s < ST_COUNT; ++s) (void)hipStreamSynchronize(r->st[s]);
+    (void)hipGetLastError();
+  }
+  r->pool.release_all();
+  r->update_flops = w.upd_flops;
+  r->update_launches = w.upd_launches;
+  r->issue_us = w.issue_us / (g.nt > 0 ? g.nt : 1);  // per wave
+  r->sends = cm ? cm->nsend : 0, r->recvs = cm ? cm->nrecv : 0, r->bytes_sent = cm ? cm->bytes_sent : 0;
+  if (rc) return rc;
+  if (info >= 0x7ffffffe) {
+    // a bounded device-side wait gave up (kernels.hip: sem_wait, k_potrf_diag): the factor is invalid.  Not a
+    // LAPACK info: a runtime failure of its own; the counter scheme stays off for the rest of this context, so
+    // a caller that regenerates and retries runs on stream events alone
+    if (r->d_sem) {
+      (void)hipFree(r->d_sem);
+      r->d_sem = nullptr;
+    }
+    return chol_internal_fail(CHOL_ERR_DEVICE_WAIT,
+                              "potrf_tile: a device-side wait on the panel chain timed out (GPU shared with a heavy co-tenant?); "
+                              "the matrix is left partly factored; device-side counters are now disabled for this context");
+  }
+  if (info > 0 && d->mbi != d->mb)  // stored index -> index in the caller's matrix
+    info = ((info - 1) / d->mbi) * d->mb + (info - 1) % d->mbi + 1;
+  return (int)info;
+}
+
+int walk_with(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool reset_ytab) {
+  if (d->mt != d->nt || d->lm != d->ln) return chol_internal_fail(-2, "potrf_tile: matrix is not square");
+  if (d->p * d->q > 1) {
+    if (!d->on_device) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: the local tiles must be device-resident");
+    if (d->mbi % MACRO) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: stored tile edge must be a multiple of 128");
+    if (!cm) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: no transport installed (chol_set_transport / chol_transport_rccl_init)");
+  }
+  return d->dtype == CHOL_REAL_DOUBLE ? walk_t<double>(d, base, r, rank, cm, reset_ytab)
+                                      : walk_t<float>(d, base, r, rank, cm, reset_ytab);
 }
 
 }  // namespace
 
 extern "C" {
+
+// called by chol_potrf_tile (api.hip) for every whole tiled matrix
+int chol_internal_walk(chol_desc *d, void *base, RankCtx *r, int rank) {
+  WaveComm cm;
+  WaveComm *pc = nullptr;
+  if (d->p * d->q > 1 && g_tr_set) {
+    cm.ch[0] = g_tr[0];
+    cm.ch[1] = g_tr[1];
+    pc = &cm;
+  }
+  return walk_with(d, base, r, rank, pc, true);
+}
+
+int chol_set_transport_channel(int channel, const chol_transport_t *t) {
+  if (channel < 0 || channel > 1) return chol_internal_fail(-1, "chol_set_transport_channel: channel must be 0 or 1");
+  if (!t || !t->group_begin || !t->send || !t->recv || !t->group_end || !t->allreduce_max)
+    return chol_internal_fail(-2, "chol_set_transport_channel: every entry of the table is required");
+  g_tr[channel] = *t;
+  return 0;
+}
 
 int chol_set_transport(const chol_transport_t *t) {
   if (!t) {
@@ -547,44 +532,63 @@ int chol_set_transport(const chol_transport_t *t) {
   }
   if (!t->group_begin || !t->send || !t->recv || !t->group_end || !t->allreduce_max)
     return chol_internal_fail(-1, "chol_set_transport: every entry of the table is required");
-  g_tr = *t;
+  g_tr[0] = g_tr[1] = *t;
   g_tr_set = true;
   return 0;
 }
 
-int chol_transport_rccl_unique_id(void *id128) {
-  if (!id128) return chol_internal_fail(-1, "rccl_unique_id: NULL");
-  RC(rccl_load());
-  nccl_uid_t id;
-  const int rc = g_rccl.GetUniqueId(&id);
-  if (rc) return rccl_fail("ncclGetUniqueId", rc);
-  memcpy(id128, &id, sizeof id);
+int chol_transport_rccl_unique_id(void *id256) {
+  if (!id256) return chol_internal_fail(-1, "rccl_unique_id: NULL");
+  WRC(rccl_load());
+  for (int c = 0; c < 2; ++c) {
+    ncclUniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy((char *)id256 + c * sizeof id, &id, sizeof id);
+  }
   return 0;
 }
 
-int chol_transport_rccl_init(const void *id128, int rank, int nranks) {
-  if (!id128) return chol_internal_fail(-1, "rccl_init: NULL id");
+int chol_transport_rccl_init(const void *id256, int rank, int nranks) {
+  if (!id256) return chol_internal_fail(-1, "rccl_init: NULL id");
   if (nranks < 1 || rank < 0 || rank >= nranks) return chol_internal_fail(-2, "rccl_init: rank");
-  RC(rccl_load());
-  if (g_rccl.comm) return chol_internal_fail(-1, "rccl_init: communicator already exists");
-  nccl_uid_t id;
-  memcpy(&id, id128, sizeof id);
-  const int rc = g_rccl.CommInitRank(&g_rccl.comm, nranks, id, rank);
-  if (rc) return rccl_fail("ncclCommInitRank", rc);
-  chol_transport_t t;
-  t.ctx = nullptr;
-  t.group_begin = rccl_group_begin;
-  t.send = rccl_send;
-  t.recv = rccl_recv;
-  t.group_end = rccl_group_end;
-  t.allreduce_max = rccl_allreduce_max;
-  return chol_set_transport(&t);
+  WRC(rccl_load());
+  if (g_rccl.comm[0]) return chol_internal_fail(-1, "rccl_init: communicators already exist");
+  for (int c = 0; c < 2; ++c) {
+    ncclUniqueId id;
+    memcpy(&id, (const char *)id256 + c * sizeof id, sizeof id);
+    const int rc = g_rccl.CommInitRank(&g_rccl.comm[c], nranks, id, rank);
+    if (rc) {
+      if (c == 1) (void)g_rccl.CommDestroy(g_rccl.comm[0]);
+      g_rccl.comm[0] = g_rccl.comm[1] = nullptr;
+      return rccl_fail("ncclCommInitRank", rc);
+    }
+  }
+  for (int c = 0; c < 2; ++c) {
+    chol_transport_t t;
+    t.ctx = &g_rccl.which[c];
+    t.group_begin = rccl_group_begin;
+    t.send = rccl_send;
+    t.recv = rccl_recv;
+    t.group_end = rccl_group_end;
+    t.allreduce_max = rccl_allreduce_max;
+    g_tr[c] = t;
+  }
+  g_tr_set = true;
+  return 0;
+}
+
+int chol_transport_rccl_version(void) {
+  if (rccl_load()) return 0;
+  return g_rccl.version;
 }
 
 int chol_transport_rccl_finalize(void) {
-  if (g_rccl.comm) {
-    (void)g_rccl.CommDestroy(g_rccl.comm);
-    g_rccl.comm = nullptr;
+  if (g_rccl.comm[0]) {
+    for (int c = 0; c < 2; ++c) {
+      if (g_rccl.comm[c]) (void)g_rccl.CommDestroy(g_rccl.comm[c]);
+      g_rccl.comm[c] = nullptr;
+    }
     g_tr_set = false;
   }
   if (g_rccl.d_red) (void)hipFree(g_rccl.d_red);
@@ -592,35 +596,54 @@ int chol_transport_rccl_finalize(void) {
   return 0;
 }
 
-int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long *recvs, long long *bytes_sent) {
-  if (issue_us_per_wave) *issue_us_per_wave = g_last_issue_us_per_wave;
-  if (sends) *sends = g_last_sends;
-  if (recvs) *recvs = g_last_recvs;
-  if (bytes_sent) *bytes_sent = g_last_bytes;
-  return 0;
+// Test hook: one message of `bytes` bytes from this rank to itself on EACH channel of the installed transport,
+// the two groups issued back to back on the walker's two communication streams (ST_CX, ST_PX), byte-compared.
+// On a one-rank RCCL communicator this is ncclSend / ncclRecv to self inside ncclGroupStart / ncclGroupEnd --
+// the transport table's entries executing on the hardware a test box has.
+int chol_transport_selftest(int self_rank, size_t bytes) {
+  if (!g_tr_set) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "transport_selftest: no transport installed");
+  if (bytes == 0 || bytes % 8) return chol_internal_fail(-2, "transport_selftest: bytes must be a positive multiple of 8");
+  RankCtx *r = main_rank_ctx();
+  if (!r->st[ST_CX]) return chol_internal_fail(CHOL_ERR_NOT_INITIALIZED, "transport_selftest before chol_init");
+  std::vector<unsigned long long> h(bytes / 8), back(bytes / 8);
+  char *dev = nullptr;
+  HIPRC(hipMalloc(&dev, 4 * bytes));
+  int rc = 0;
+  const int sts[2] = {ST_CX, ST_PX};
+  for (int c = 0; c < 2 && !rc; ++c) {
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0x9e3779b97f4a7c15ull * (i + 1 + 7919 * c);
+    if (hipMemcpy(dev + 2 * c * bytes, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(dev + (2 * c + 1) * bytes, 0, bytes) != hipSuccess)
+      rc = chol_internal_fail(CHOL_ERR_HIP, "transport_selftest: upload");
+  }
+  for (int c = 0; c < 2 && !rc; ++c) {  // both groups in flight before either is waited for
+    hipStream_t s = r->st[sts[c]];
+    rc = g_tr[c].group_begin(g_tr[c].ctx);
+    if (!rc) rc = g_tr[c].send(g_tr[c].ctx, dev + 2 * c * bytes, bytes, self_rank, s);
+    if (!rc) rc = g_tr[c].recv(g_tr[c].ctx, dev + (2 * c + 1) * bytes, bytes, self_rank, s);
+    const int rc2 = g_tr[c].group_end(g_tr[c].ctx);
+    if (!rc) rc = rc2;
+  }
+  for (int c = 0; c < 2; ++c)
+    if (hipStreamSynchronize(r->st[sts[c]]) != hipSuccess && !rc) rc = chol_internal_fail(CHOL_ERR_HIP, "transport_selftest: synchronize");
+  for (int c = 0; c < 2 && !rc; ++c) {
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0x9e3779b97f4a7c15ull * (i + 1 + 7919 * c);
+    if (hipMemcpy(back.data(), dev + (2 * c + 1) * bytes, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = chol_internal_fail(CHOL_ERR_HIP, "transport_selftest: download");
+    else if (memcmp(back.data(), h.data(), bytes) != 0)
+      rc = chol_internal_fail(CHOL_ERR_HIP, c == 0 ? "transport_selftest: channel 0 delivered different bytes" : "transport_selftest: channel 1 delivered different bytes");
+  }
+  (void)hipFree(dev);
+  return rc;
 }
 
-// called by chol_potrf_tile (api.hip) for descriptors with p*q > 1
-int chol_internal_dist_potrf(chol_desc *d, int rank) {
-  if (!d->on_device) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: the local tiles must be device-resident");
-  if (d->mt != d->nt || d->lm != d->ln) return chol_internal_fail(-2, "potrf_tile: matrix is not square");
-  if (d->padded || d->mbi != d->mb || d->lm % d->mb) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: order must be a multiple of the tile, tile a multiple of 128");
-  RC(hip_ready());
-  HipEngine eng(d, rank);
-  Dist dist(eng, g_tr_set ? &g_tr : nullptr);
-  int rc = dist.setup();
-  long long info = 0;
-  static const bool lookahead = !(getenv("CHOLMI_DIST_LOOKAHEAD") && atoi(getenv("CHOLMI_DIST_LOOKAHEAD")) == 0);
-  if (!rc) rc = dist.factorize(lookahead, &info);
-  if (rc) {  // leave nothing half-open behind a failure: close the transport group, drain the streams
-    (void)dist.end();
-    (void)eng.sync();
-  }
-  g_pool.release_all();
-  g_last_issue_us_per_wave = dist.issue_us / (eng.nt > 0 ? eng.nt : 1);
-  g_last_sends = dist.nsend, g_last_recvs = dist.nrecv, g_last_bytes = dist.bytes_sent;
-  if (rc) return rc;
-  return (int)info;
+int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long *recvs, long long *bytes_sent) {
+  RankCtx *r = main_rank_ctx();
+  if (issue_us_per_wave) *issue_us_per_wave = r->issue_us;
+  if (sends) *sends = r->sends;
+  if (recvs) *recvs = r->recvs;
+  if (bytes_sent) *bytes_sent = r->bytes_sent;
+  return 0;
 }
 
 // Collect the lower tiles of a p x q descriptor on `root` into a single-process descriptor of the same
@@ -636,9 +659,9 @@ int chol_dist_gather_lower(chol_desc_t *src, chol_desc_t *dst, int root) {
       return chol_internal_fail(-2, "dist_gather_lower: destination must be a device-resident 1 x 1 descriptor of the same order, tile and type");
   }
   if (world > 1 && !g_tr_set) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "dist_gather_lower: no transport installed");
-  RC(hip_ready());
   const size_t tb = (size_t)src->bsizi * src->esize;
-  hipStream_t st = g_streams[S_MAIN];
+  hipStream_t st = main_rank_ctx()->st[ST_MAIN];
+  chol_transport_t &tr = g_tr[1];
   for (int J = 0; J < src->nt; ++J) {
     bool grouped = false;
     for (int I = J; I < src->mt; ++I) {
@@ -650,48 +673,143 @@ int chol_dist_gather_lower(chol_desc_t *src, chol_desc_t *dst, int root) {
           return chol_internal_fail(CHOL_ERR_HIP, "dist_gather_lower: copy");
       } else if (owner == rank || rank == root) {
         if (!grouped) {
-          RC(g_tr.group_begin(g_tr.ctx));
+          WRC(tr.group_begin(tr.ctx));
           grouped = true;
         }
         if (owner == rank)
-          RC(g_tr.send(g_tr.ctx, mine, tb, root, st));
+          WRC(tr.send(tr.ctx, mine, tb, root, st));
         else
-          RC(g_tr.recv(g_tr.ctx, there, tb, owner, st));
+          WRC(tr.recv(tr.ctx, there, tb, owner, st));
       }
     }
-    if (grouped) RC(g_tr.group_end(g_tr.ctx));
+    if (grouped) WRC(tr.group_end(tr.ctx));
   }
   return hipStreamSynchronize(st) == hipSuccess ? 0 : chol_internal_fail(CHOL_ERR_HIP, "dist_gather_lower: synchronize");
 }
 
-void chol_internal_dist_finalize(void) {
-  (void)chol_transport_rccl_finalize();
-  g_pool.free_all();
-  if (g_hip_ready) {
-    for (int s = 0; s < 3; ++s) (void)hipStreamDestroy(g_streams[s]);
-    for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(g_events[i]);
-    g_hip_ready = false;
-  }
-}
+void chol_internal_dist_finalize(void) { (void)chol_transport_rccl_finalize(); }
 
+// Test hook (include/cholmi.h): the walker over caller-supplied tile kernels.
+// mode: 0 every wave plain and split (near / far halves), 1 mixed (pairs while a rank has >= 6 tiles to update),
+// 2 every wave in pairs, none split -- the regimes the product picks by measured speed, forced here
 int chol_dist_factorize_with(const chol_test_engine_t *engine, const chol_transport_t *transport, int N, int B,
-                             int p, int q, int rank, int lookahead) {
+                             int p, int q, int rank, int mode) {
   if (!engine || !engine->store || !engine->alloc || !engine->potrf || !engine->trsm || !engine->update ||
       !engine->update_diag || !engine->info)
     return chol_internal_fail(-1, "dist_factorize_with: engine table incomplete");
   if (p * q > 1 && !transport) return chol_internal_fail(-2, "dist_factorize_with: transport required");
-  if (N <= 0 || B <= 0 || N % B || p <= 0 || q <= 0 || p > cholmi::MAXP || rank < 0 || rank >= p * q)
+  if (N <= 0 || B <= 0 || N % B || p <= 0 || q <= 0 || p > MAXP || rank < 0 || rank >= p * q)
     return chol_internal_fail(-3, "dist_factorize_with: geometry");
-  CbEngine eng(*engine, N, B, p, q, rank);
-  Dist dist(eng, transport);
+  WaveGeo g;
+  g.init(N / B, B, p, q, rank, engine->esize);
+  g.winv_bytes = 0;
+  CbOps ops(*engine, g);
+  WaveComm cm;
+  if (transport) cm.ch[0] = cm.ch[1] = *transport;
+  WaveCalib c;
+  c.t_tile = 1.0;
+  c.t_panel = mode == 0 ? 1e30 : mode == 1 ? 3.0 : 1e-30;
+  Walker<CbOps> w(ops, g, p * q > 1 ? &cm : nullptr, c);
   long long info = 0;
-  int rc = dist.setup();
-  if (!rc) rc = dist.factorize(lookahead != 0, &info);
-  if (rc) (void)dist.end();
-  g_last_issue_us_per_wave = dist.issue_us / (eng.nt > 0 ? eng.nt : 1);
-  g_last_sends = dist.nsend, g_last_recvs = dist.nrecv, g_last_bytes = dist.bytes_sent;
+  int rc = w.setup();
+  if (!rc) rc = w.run(&info);
+  if (rc && transport) (void)cm.end(0), (void)cm.end(1);
+  RankCtx *r = main_rank_ctx();
+  r->issue_us = w.issue_us / (g.nt > 0 ? g.nt : 1);  // per wave
+  r->sends = cm.nsend, r->recvs = cm.nrecv, r->bytes_sent = cm.bytes_sent;
   if (rc) return rc;
   return (int)info;
+}
+
+// Test hook: a p x q factorisation rehearsed on ONE GPU -- p*q ranks as threads of this process, each with its
+// own streams, workspaces and local tiles, the real kernels, the in-process asynchronous transport above.  The
+// matrix is plgsy(bump, seed) of order N; the factor's lower tiles are gathered into `full` (a device-resident
+// 1 x 1 descriptor of the same order, tile size and type).  *ms: wall time of the factorisation (all ranks share
+// the GPU: a stress figure, not a scaling figure).  Returns the LAPACK info all ranks agreed on.
+int chol_dist_rehearse(int dtype, int N, int mb, int p, int q, double bump, unsigned long long seed,
+                       chol_desc_t *full, double *ms) {
+  RankCtx *mr = main_rank_ctx();
+  if (!mr->st[ST_MAIN]) return chol_internal_fail(CHOL_ERR_NOT_INITIALIZED, "dist_rehearse before chol_init");
+  const int R = p * q;
+  if (p < 1 || q < 1 || p > MAXP || R > 16) return chol_internal_fail(-4, "dist_rehearse: grid");
+  if (N <= 0 || mb <= 0 || N % mb || mb % MACRO) return chol_internal_fail(-2, "dist_rehearse: N must be a multiple of mb, mb of 128");
+  if (!full || full->p * full->q != 1 || full->lm != N || full->mbi != mb || full->dtype != dtype || !full->on_device)
+    return chol_internal_fail(-8, "dist_rehearse: `full` must be a device-resident 1 x 1 descriptor of order N, tile mb, same type");
+  std::vector<RankCtx> ctx(R);
+  std::vector<chol_desc_t *> desc(R, nullptr);
+  std::vector<HubEnd> ends(2 * R);
+  Hub hub;
+  hub.nranks = R;
+  int rc = 0;
+  const int nt = N / mb;
+  const size_t tb = (size_t)mb * mb * (dtype == CHOL_REAL_DOUBLE ? 8 : 4);
+  // staging for everything that is ever sent: every panel tile to at most p + q - 2 peers, plus diagonal and head tiles
+  hub.arena_bytes = (size_t)nt * (nt + 1) / 2 * tb * (size_t)std::max(1, p + q - 2) + (size_t)4 * nt * p * tb + (64u << 20);
+  if (hipMalloc(&hub.arena, hub.arena_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    hub.arena = nullptr;  // falls back to one allocation per message
+  }
+  for (int r = 0; r < R && !rc; ++r) {
+    rc = rank_ctx_create(&ctx[r], mr->device, mr);
+    if (!rc) rc = chol_internal_desc_create(&desc[r], nullptr, dtype, mb, mb, mb * mb, N, N, 0, 0, N, N, p, q, r, R);
+    if (!rc) rc = chol_plgsy_tile(bump, CHOL_LOWER, desc[r], seed);
+    for (int c = 0; c < 2; ++c) ends[2 * r + c] = HubEnd{&hub, r, c};
+  }
+  std::vector<int> res(R, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!rc) {
+    if (g_ytab) (void)hipMemset(g_ytab, 0, YTAB_ENTRIES * sizeof(int));
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r)
+      th.emplace_back([&, r] {
+        (void)hipSetDevice(mr->device);
+        WaveComm cm;
+        for (int c = 0; c < 2; ++c) {
+          chol_transport_t t;
+          t.ctx = &ends[2 * r + c];
+          t.group_begin = hub_group;
+          t.send = hub_send;
+          t.recv = hub_recv;
+          t.group_end = hub_group;
+          t.allreduce_max = hub_allreduce_max;
+          cm.ch[c] = t;
+        }
+        res[r] = walk_with(desc[r], desc[r]->mat, &ctx[r], r, R > 1 ? &cm : nullptr, false);
+        if (res[r] < 0) {
+          std::lock_guard<std::mutex> lk(hub.mu);
+          hub.failed = true;
+          hub.cv.notify_all();
+        }
+      });
+    for (auto &t : th) t.join();
+  }
+  if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  (void)hipDeviceSynchronize();
+  if (!rc) {
+    for (int r = 0; r < R; ++r)
+      if (res[r] < 0 || (res[r] != res[0] && !rc)) rc = res[r] < 0 ? res[r] : chol_internal_fail(CHOL_ERR_HIP, "dist_rehearse: ranks disagree on info");
+    if (!rc) rc = res[0];
+  }
+  if (rc >= 0) {  // gather the lower tiles
+    for (int J = 0; J < nt; ++J)
+      for (int I = J; I < nt; ++I) {
+        chol_desc_t *s = desc[(I % p) * q + J % q];
+        const char *src = (const char *)s->mat + ((size_t)(I / p) + (size_t)(J / q) * s->lmt) * tb;
+        char *dst = (char *)full->mat + ((size_t)I + (size_t)J * full->lmt) * tb;
+        if (hipMemcpyAsync(dst, src, tb, hipMemcpyDeviceToDevice, mr->st[ST_MAIN]) != hipSuccess)
+          rc = chol_internal_fail(CHOL_ERR_HIP, "dist_rehearse: gather");
+      }
+    (void)hipStreamSynchronize(mr->st[ST_MAIN]);
+  }
+  for (int r = 0; r < R; ++r) {
+    if (desc[r]) (void)chol_desc_destroy(&desc[r]);
+    if (ctx[r].st[ST_MAIN]) {
+      mr->sends = ctx[0].sends, mr->recvs = ctx[0].recvs, mr->bytes_sent = ctx[0].bytes_sent, mr->issue_us = ctx[0].issue_us;
+      rank_ctx_destroy(&ctx[r]);
+    }
+  }
+  hub.release();
+  return rc;
 }
 
 }  // extern "C"

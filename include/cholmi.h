@@ -66,7 +66,8 @@ enum {
   CHOL_ERR_NO_GPU = -102,        /* no HIP device / ngpu == 0 requested */
   CHOL_ERR_HIP = -103,           /* a HIP runtime call failed (see chol_last_error) */
   CHOL_ERR_NOT_SUPPORTED = -104, /* valid Chameleon usage this build does not cover */
-  CHOL_ERR_OUT_OF_MEMORY = -105
+  CHOL_ERR_OUT_OF_MEMORY = -105,
+  CHOL_ERR_DEVICE_WAIT = -106    /* a bounded device-side wait inside the library gave up: the result is invalid */
 };
 
 typedef struct chol_desc chol_desc_t;
@@ -99,9 +100,10 @@ int chol_desc_destroy(chol_desc_t **desc);
  * ChamLower; needs a transport, see chol_set_transport below).  ChamUpper is served for device-resident
  * matrices by transposing the storage in place around the Lower factorisation (the strict
  * lower triangle is returned untouched).
- * Returns LAPACK's info (0, or the 1-based index of the first non-positive pivot), a negative CHOL_ERR_*,
- * or -- never expected -- INT_MAX / INT_MAX - 1: a bounded device-side wait inside the library gave up
- * (the factor is then invalid). */
+ * Returns LAPACK's info (0, or the 1-based index of the first non-positive pivot) or a negative CHOL_ERR_*;
+ * CHOL_ERR_DEVICE_WAIT -- never expected -- says that a bounded device-side wait inside the library gave
+ * up (the matrix is then left partly factored; the context falls back to stream events for later calls;
+ * DESIGN.md, section 4). */
 int chol_potrf_tile(int uplo, chol_desc_t *A);
 
 /* CHAMELEON_dtrsm_Tile(side, uplo, trans, diag, alpha, A, B) W2:323.
@@ -195,52 +197,36 @@ int chol_debug_stamps(int enable, unsigned long long *out, int max_pairs);
  * rate this chip sustains under load, to quote beside the datasheet peak. */
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);
 
-/* ---- distributed (one process per GPU) building blocks -------------------- */
-/* Used by the Python driver that moves panel tiles with torch.distributed
- * (RCCL).  All are asynchronous on the stream passed as `stream` (a hipStream_t
- * cast to void*; NULL = the HIP null stream).  `k` is the wave index. */
+/* What the walker's regime switches (pairs / halves / counter-linked chain / CU hand-over) are measured in,
+ * taken once at chol_init (or from CHOLMI_CALIB="tf64,us64,tf32,us32"): out8[0..3] = fp64 MFMA probe
+ * [TFLOP/s], fp64 128 x 128 diagonal-block step alone [us], the same for fp32; out8[4..7] = the derived
+ * update rate inside the DAG [TFLOP/s] and panel-chain step [us] per dtype that the thresholds use. */
+int chol_debug_calibration(double *out8);
+/* Name of the trailing-update kernel launched for `dtype` under the current CHOLMI_VARIANT / CHOLMI_F32_W8
+ * switches, as a profiler prints it (bench.py's roofline.kernel). */
+int chol_debug_update_kernel(int dtype, char *buf, int buflen);
+
+/* ---- local storage of a descriptor ---------------------------------------- */
 void *chol_desc_local_ptr(chol_desc_t *desc, size_t *bytes);
 int chol_desc_local_tiles(chol_desc_t *desc, int *lmt, int *lnt);
-/* POTRF of tile (k,k) in place (owner only) and its 128-block inverses into the
- * context workspace; `lkk` = device pointer to the tile. */
-int chol_wave_potrf(chol_desc_t *desc, int k, void *lkk, void *stream);
-/* After the diagonal tile arrived by broadcast on a non-owner: rebuild the
- * 128-block inverses from the received L(k,k). */
-int chol_wave_invert_diag(chol_desc_t *desc, void *lkk, void *stream);
-/* The 128-block inverses that chol_wave_potrf left in the context, as bytes to ship beside
- * L(k,k) (export on the owner, import on the receivers) instead of chol_wave_invert_diag. */
-size_t chol_wave_winv_bytes(chol_desc_t *desc);
-int chol_wave_export_winv(chol_desc_t *desc, void *dst, void *stream);
-int chol_wave_import_winv(chol_desc_t *desc, const void *src, void *stream);
-/* TRSM of this process's tiles (i,k), i > k, against `lkk`. */
-int chol_wave_trsm(chol_desc_t *desc, int k, const void *lkk, void *stream);
-/* Trailing update of this process's tiles (i,j), j in [jlo, jhi), i >= j, i > k,
- * with panel tile i read from panel_base[i % p] + (i/p - panel_first[i % p])*bsiz.
- * skip_diag != 0: leave out tile (jlo, jlo) -- its owner has already updated (and factored)
- * it ahead of the rest with chol_wave_update_diag. */
-int chol_wave_update(chol_desc_t *desc, int k, int jlo, int jhi, const void *const *panel_base,
-                     const int *panel_first, int skip_diag, void *stream);
-/* The one SYRK  C(j,j) -= L(j,k) L(j,k)^T  on the owner of (j,j), as soon as L(j,k) has
- * arrived (panel_base[j % p] / panel_first[j % p] address it): lets POTRF(j) start while
- * the rest of panel k is still on the wire. */
-int chol_wave_update_diag(chol_desc_t *desc, int k, int j, const void *const *panel_base,
-                          const int *panel_first, void *stream);
-int chol_get_info(int *info); /* device-side POTRF status word of the current factorisation */
-int chol_reset_info(void);
 
 /* ---- distributed factorisation behind chol_potrf_tile --------------------- */
 /* chol_potrf_tile(ChamLower, A) on a descriptor with p*q > 1 (the reference passes p, q from argv
  * straight into CHAMELEON_Desc_Create, V6:26-27, 44-45) runs the 2D block-cyclic wave DAG of all
- * p*q processes inside the library: the wave loop is C++ (no per-wave host-language code), the tiles
- * move through the transport installed below.  Per wave: L(k,k) (with its block inverses) goes from
- * its owner to the other ranks of its process column; every panel tile L(i,k) goes along process
- * row i mod p (whole contiguous parts) and to the ranks of process column i mod q (tile by tile) --
- * point to point, one group per wave; nobody receives a tile it does not use.
+ * p*q processes inside the library -- the SAME wave walker as on one GPU (csrc/walker.h; p = q = 1 is its
+ * instance without transport calls): paired panels, near / far halves, the POTRF steps pipelined with the
+ * owner's TRSM steps.  What moves per wave, point to point, nobody receiving a tile it does not use:
+ * L(k,k) with its block inverses from its owner to the other ranks of its process column; the head tile
+ * L(k+1,k) ahead of everything else to the owner of (k+1,k+1); every panel tile L(i,k) along process row
+ * i mod p (whole contiguous parts) and to the ranks of process column i mod q (tile by tile).
  *
  * A transport is a table of stream-ordered point-to-point operations.  `stream` is a hipStream_t;
  * everything issued between group_begin and group_end progresses together (ncclGroupStart /
  * ncclGroupEnd semantics: sends and receives of one group may be matched in any order).
- * allreduce_max is a blocking host-value reduction (the final LAPACK info). */
+ * allreduce_max is a blocking host-value reduction (the final LAPACK info).
+ * The walker drives TWO channels from two streams of its own: channel 0 carries the small latency-critical
+ * messages (diagonal tile, head tile), channel 1 the panel exchange -- so that a communicator which executes
+ * its operations in issue order (RCCL does) never queues the next diagonal tile behind a panel. */
 typedef struct chol_transport {
   void *ctx;
   int (*group_begin)(void *ctx);
@@ -249,15 +235,21 @@ typedef struct chol_transport {
   int (*group_end)(void *ctx);
   int (*allreduce_max)(void *ctx, long long *value);
 } chol_transport_t;
-/* Install (copy) a transport; NULL removes it.  Ranks are those of chol_set_rank. */
+/* Install (copy) a transport for both channels; NULL removes it.  Ranks are those of chol_set_rank.
+ * chol_set_transport_channel replaces the table of one channel (0 or 1) afterwards. */
 int chol_set_transport(const chol_transport_t *t);
-/* The RCCL transport (xGMI inside a node): rank 0 creates the 128-byte id, the application shares it
- * out of band (MPI, torch.distributed store, a file), every rank calls _init -- which builds the
- * communicator on this process's device and installs the transport (ncclSend / ncclRecv in
- * ncclGroupStart / ncclGroupEnd).  librccl is loaded at this call, not at link time. */
-int chol_transport_rccl_unique_id(void *id128);
-int chol_transport_rccl_init(const void *id128, int rank, int nranks);
+int chol_set_transport_channel(int channel, const chol_transport_t *t);
+/* The RCCL transport (xGMI inside a node): rank 0 creates the id blob (CHOL_RCCL_ID_BYTES: one ncclUniqueId
+ * per channel), the application shares it out of band (MPI, torch.distributed store, a file), every rank calls
+ * _init -- which builds one communicator per channel on this process's device and installs the transport
+ * (ncclSend / ncclRecv in ncclGroupStart / ncclGroupEnd).  librccl is loaded at this call, not at link
+ * time; its version (ncclGetVersion) must match the major version of the rccl.h this library was compiled
+ * against and be >= 2.7 (point-to-point operations); _version returns the code (0: not loadable). */
+#define CHOL_RCCL_ID_BYTES 256
+int chol_transport_rccl_unique_id(void *id256);
+int chol_transport_rccl_init(const void *id256, int rank, int nranks);
 int chol_transport_rccl_finalize(void);
+int chol_transport_rccl_version(void);
 /* Host time spent issuing the last distributed factorisation (everything but the final
  * synchronisation), in microseconds per wave, and the number of transport operations it posted. */
 int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long *recvs, long long *bytes_sent);
@@ -267,11 +259,18 @@ int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long 
  * root verify a distributed factorisation with chol_residual_plgsy.  Collective over the p*q ranks. */
 int chol_dist_gather_lower(chol_desc_t *src, chol_desc_t *dst, int root);
 
-/* Test hook: the same C++ wave loop over caller-supplied tile kernels, so that the distribution
- * logic (ownership, addressing, matching of sends and receives, buffer reuse) can run without a
- * GPU under any transport.  NOT a compute path of the product: chol_potrf_tile never uses it.
- * Tiles are addressed as in a descriptor: local tile (il, jl) of an lmt x lnt local grid at
- * store + (il + jl*lmt) * B*B elements.  All callbacks are synchronous. */
+/* ---- test hooks of the distributed path (never used by chol_potrf_tile) --- */
+/* One message of `bytes` bytes (a positive multiple of 8) from this rank to itself on EACH channel of the
+ * installed transport, both groups in flight together on the walker's two communication streams,
+ * byte-compared.  On a one-rank RCCL communicator: ncclSend / ncclRecv to self inside one group. */
+int chol_transport_selftest(int self_rank, size_t bytes);
+
+/* The wave walker over caller-supplied tile kernels, so that the distribution logic (ownership,
+ * addressing, matching of sends and receives, buffer reuse, the paired / halves regimes) can run without
+ * a GPU under any transport.  Tiles are addressed as in a descriptor: local tile (il, jl) of an
+ * lmt x lnt local grid at store + (il + jl*lmt) * B*B elements.  All callbacks are synchronous and are
+ * called in a valid sequential order.  mode: 0 every wave plain and split, 1 mixed (panels in pairs while a
+ * rank has >= 6 tiles to update), 2 every wave in pairs -- the regimes the product picks by measured speed. */
 typedef struct chol_test_engine {
   void *ctx;
   void *store;      /* this rank's tiles */
@@ -284,7 +283,17 @@ typedef struct chol_test_engine {
   int (*info)(void *ctx);
 } chol_test_engine_t;
 int chol_dist_factorize_with(const chol_test_engine_t *engine, const chol_transport_t *transport, int N, int B,
-                             int p, int q, int rank, int lookahead);
+                             int p, int q, int rank, int mode);
+
+/* A p x q factorisation rehearsed on ONE GPU: p*q ranks as threads of this process, each with its own
+ * streams, workspaces and local tiles, the real kernels, and an in-process transport whose sends and receives
+ * are stream-ordered device copies (no device synchronisation anywhere: the stream / event ordering and the
+ * buffer reuse of the multi-GPU schedule are what is exercised).  The matrix is plgsy(bump, seed) of order N
+ * (a multiple of mb, mb a multiple of 128); the factor's lower tiles are gathered into `full`, a
+ * device-resident 1 x 1 descriptor of the same order, tile size and type.  *ms: wall time (the ranks share the
+ * GPU: a stress figure, not a scaling figure).  Returns the LAPACK info the ranks agreed on. */
+int chol_dist_rehearse(int dtype, int N, int mb, int p, int q, double bump, unsigned long long seed,
+                       chol_desc_t *full, double *ms);
 
 #ifdef __cplusplus
 }

@@ -1,10 +1,11 @@
-"""The C++ distributed wave loop (csrc/dist.hip, the code behind chol_potrf_tile on a p x q
-descriptor) driven on the CPU: the oracle's tile kernels plugged in through the library's test hook
+"""The wave walker (csrc/walker.h, the code behind chol_potrf_tile on every whole tiled matrix, one GPU or a
+p x q grid) driven on the CPU: the oracle's tile kernels plugged in through the library's test hook
 (chol_dist_factorize_with), the tiles moved by a torch.distributed/gloo transport table -- ownership,
 local indexing, matching of the point-to-point sends and receives along process rows and columns,
-receive-buffer reuse and the lookahead order are exactly the multi-GPU code path; no compute of the
-product runs here.  World sizes 2 (1x2), 4 (2x2), 6 (2x3), 8 (2x4); the result must equal the
-single-process oracle and every rank must report the same info."""
+receive-buffer reuse, and the schedule's regimes (panels in pairs, near / far halves, plain waves: `mode`)
+are exactly the product's code path; no compute of the product runs here.  World sizes 1, 2 (1x2), 3 (1x3),
+4 (2x2), 6 (2x3), 8 (2x4) and the tall grids 2x1, 3x1; the result must equal the single-process oracle and
+every rank must report the same info."""
 import ctypes as C
 import os
 import socket
@@ -119,7 +120,7 @@ class OracleCEngine:
         return 0
 
 
-def _worker(rank, world, port, N, B, lookahead, bad, q):
+def _worker(rank, world, port, N, B, mode, bad, q, grid):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -128,7 +129,7 @@ def _worker(rank, world, port, N, B, lookahead, bad, q):
     from dense_linear_app_amd._lib import lib
     from oracle import oracle as orc
 
-    P, Q = dd.grid_for(world)
+    P, Q = grid if grid else dd.grid_for(world)
     eng = OracleCEngine(orc, N, B, P, Q, rank)
     eng.generate(float(N), 42)
     if bad is not None:
@@ -136,7 +137,7 @@ def _worker(rank, world, port, N, B, lookahead, bad, q):
         if dd.owner_of(I, I, P, Q) == rank:
             eng.tile(I // P, I // Q)[bad % B, bad % B] = -3.0
     tr = dd.TorchTransport(dist, device=None)
-    info = lib().chol_dist_factorize_with(C.byref(eng.table), C.byref(tr.table), N, B, P, Q, rank, int(lookahead))
+    info = lib().chol_dist_factorize_with(C.byref(eng.table), C.byref(tr.table), N, B, P, Q, rank, int(mode))
     stats = dd.dist_last_stats()
     tiles = {}
     for I in range(eng.nt):
@@ -148,11 +149,11 @@ def _worker(rank, world, port, N, B, lookahead, bad, q):
     dist.destroy_process_group()
 
 
-def _run(world, N, B, lookahead=True, bad=None):
+def _run(world, N, B, mode=1, bad=None, grid=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, lookahead, bad, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, mode, bad, q, grid)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
@@ -162,12 +163,14 @@ def _run(world, N, B, lookahead=True, bad=None):
     return got
 
 
-@pytest.mark.parametrize("world,lookahead", [(1, True), (2, True), (2, False), (4, True), (4, False), (6, True), (8, True)])
-def test_c_wave_loop_matches_oracle(world, lookahead):
+@pytest.mark.parametrize("world,mode,grid", [(1, 0, None), (1, 1, None), (1, 2, None), (2, 1, None), (2, 0, None), (2, 2, None),
+                                             (4, 1, None), (4, 0, None), (4, 2, None), (6, 1, None), (8, 1, None), (8, 2, None),
+                                             (2, 1, (2, 1)), (3, 1, (3, 1)), (3, 2, (1, 3)), (6, 0, (3, 2))])
+def test_c_wave_loop_matches_oracle(world, mode, grid):
     from oracle import oracle as orc
 
-    N, B = 112, 16  # 7 tiles per side: ragged parts, every residue class of (i mod p, j mod q)
-    got = _run(world, N, B, lookahead)
+    N, B = 176, 16  # 11 tiles per side: ragged parts, every residue class of (i mod p, j mod q), > 2 buffer rotations
+    got = _run(world, N, B, mode, grid=grid)
     T = orc.plgsy_tiles(N // B, B, float(N), 42)
     assert orc.tiled_potrf(T, N // B, B) == 0
     Lref = orc.tile_to_lapack(T, N, B)
@@ -185,7 +188,7 @@ def test_c_wave_loop_matches_oracle(world, lookahead):
     sends = sum(s["sends"] for *_, s in got)
     recvs = sum(s["recvs"] for *_, s in got)
     assert sends == recvs
-    if world == 8:
+    if world == 8 and mode == 1:
         nt, tile = N // B, B * B * 8
         replicated = sum((nt - 1 - k) * tile * (world - 1) for k in range(nt))
         moved = sum(s["bytes_sent"] for *_, s in got)
@@ -193,7 +196,7 @@ def test_c_wave_loop_matches_oracle(world, lookahead):
 
 
 def test_c_wave_loop_info_is_agreed_by_all_ranks():
-    got = _run(4, 64, 16, True, bad=37)
+    got = _run(4, 64, 16, 1, bad=37)
     assert [info for _, info, _, _ in got] == [38, 38, 38, 38]
 
 

@@ -198,9 +198,6 @@ def test_tile_above_workspace_capacity_is_refused(cham):
     before = a.copy()
     assert L.chol_potrf_tile(ch.ChamLower, d) == -104 and b"4096" in L.chol_last_error()
     assert L.chol_trsm_tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, d, d) == -104
-    assert L.chol_wave_potrf(d, 0, a.ctypes.data, None) == -104
-    assert L.chol_wave_invert_diag(d, a.ctypes.data, None) == -104
-    assert L.chol_wave_trsm(d, 0, a.ctypes.data, None) == -104
     assert np.array_equal(a, before)
     assert L.chol_desc_destroy(C.byref(d)) == 0
     # the largest tile that fits still works
