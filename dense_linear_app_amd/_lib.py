@@ -76,7 +76,11 @@ def lib() -> C.CDLL:
         "chol_transport_rccl_version": ([], i),
         "chol_set_transport_channel": ([i, vp], i),
         "chol_transport_selftest": ([i, C.c_size_t], i),
+        "chol_set_transport_null": ([], i),
         "chol_dist_rehearse": ([i, i, i, i, i, d, u64, vp, C.POINTER(d)], i),
+        "chol_desc_set_version": ([vp, u64], i),
+        "chol_tile_batch": ([i, i, i, i, vp, vp, vp, vp, i], i),
+        "chol_sync": ([], i),
         "chol_debug_calibration": ([C.POINTER(d)], i),
         "chol_debug_update_kernel": ([i, C.c_char_p, i], i),
         "chol_dist_last_stats": ([C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i),

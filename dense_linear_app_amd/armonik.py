@@ -111,6 +111,11 @@ class DeviceBlob:
         return cls(torch.from_numpy(a.copy()).cuda())
 
     def to_bytes(self) -> bytes:
+        # the tile may still be in flight on the library's own stream (worker.ExecuteBatch issues whole op classes
+        # asynchronously): wait for that stream before torch copies on its own
+        from ._lib import lib
+
+        lib().chol_sync()
         return self.tensor.cpu().numpy().tobytes()
 
 
@@ -199,8 +204,11 @@ class _Task:
 class ControlPlane:
     """What stands between the four clients and the worker(s)."""
 
-    def __init__(self, device_results: bool = False):
+    def __init__(self, device_results: bool = False, batch_ready: bool = False):
         self.device_results = device_results
+        # batch_ready: all tasks that are ready together go to the worker's ExecuteBatch in one call (the agent of
+        # the reference drives one Execute at a time, W2:593; this is the wave-level execution of SURVEY 8f.3)
+        self.batch_ready = batch_ready
         self._sessions: Dict[str, TaskOptions] = {}
         self._results: Dict[str, _Result] = {}
         self._tasks: Dict[str, _Task] = {}
@@ -258,10 +266,50 @@ class ControlPlane:
         if self.on_task_done:
             self.on_task_done(t)
 
+    def _run_batch(self, tasks: List[_Task]) -> None:
+        """Hand every ready task of one partition to its worker at once (wave-level execution).  The
+        worker answers with one ProcessStatus per task; bookkeeping per task is that of _run."""
+        worker = self._workers.get(tasks[0].options.partition_id)
+        try:
+            statuses = worker.ExecuteBatch([TaskHandler(self, t.session_id, t) for t in tasks])
+            if len(statuses) != len(tasks):
+                raise RuntimeError("ExecuteBatch returned a status list of the wrong length")
+        except Exception:  # a crashing batch: fall back to the one-task path with its retry rule
+            for t in tasks:
+                if t.status == "pending" and not any(self._results[k].status == "completed" for k in t.expected_output_keys):
+                    self._run(t)
+            return
+        for t, status in zip(tasks, statuses):
+            t.attempts += 1
+            t.output = status
+            missing = [k for k in t.expected_output_keys if self._results[k].status != "completed"]
+            if status.ok() and not missing:
+                t.status = "completed"
+            else:
+                t.status = "error"
+                if status.ok():
+                    t.output = ProcessStatus("task returned Ok without producing " + ",".join(missing))
+                for k in missing:
+                    self._results[k].status = "aborted"
+            self.executed.append(t.task_id)
+            if self.on_task_done:
+                self.on_task_done(t)
+
     def _pump(self) -> None:
         progressed = True
         while progressed:
             progressed = False
+            if self.batch_ready:
+                ready = [self._tasks[tid] for tid in self._pending if self._ready(self._tasks[tid])]
+                by_part: Dict[str, List[_Task]] = {}
+                for t in ready:
+                    by_part.setdefault(t.options.partition_id, []).append(t)
+                for part, ts in by_part.items():
+                    if len(ts) > 1 and hasattr(self._workers.get(part), "ExecuteBatch"):
+                        for t in ts:
+                            self._pending.remove(t.task_id)
+                        self._run_batch(ts)
+                        progressed = True
             for tid in list(self._pending):
                 t = self._tasks[tid]
                 if self._blocked_forever(t):

@@ -110,6 +110,10 @@ class Desc:
         p = lib().chol_desc_local_ptr(self.handle, C.byref(n))
         return int(p or 0), int(n.value)
 
+    def set_version(self, version: int) -> None:
+        """Name the content behind this 1-tile descriptor's device buffer (chol_desc_set_version)."""
+        check("chol_desc_set_version", lib().chol_desc_set_version(self._h, C.c_ulonglong(int(version) & (2 ** 64 - 1))))
+
     def local_tiles(self) -> tuple[int, int]:
         a, b = C.c_int(), C.c_int()
         check("chol_desc_local_tiles", lib().chol_desc_local_tiles(self.handle, C.byref(a), C.byref(b)))

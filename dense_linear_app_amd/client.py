@@ -211,7 +211,8 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
     wait_for_result_availability per phase of a wave (POTRF; all TRSM; all SYRK/GEMM) instead of
     four blocking calls per task (C2:471-499)."""
     if plane is None:
-        plane = ak.ControlPlane(device_results=device_results)
+        # batched: the tasks that become ready together reach the worker in one ExecuteBatch call (wave-level execution)
+        plane = ak.ControlPlane(device_results=device_results, batch_ready=batched)
     if worker is None:
         from .worker import DagCholeskyWorker
 
@@ -298,6 +299,10 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
                     keys.append(block_id_from_ij(i, j))
             for key, o in zip(keys, submit_batch(items)):
                 latest[key] = o
+        if device_results:  # grouped launches are asynchronous on the library's stream: the run ends when they have
+            from ._lib import lib
+
+            lib().chol_sync()
         return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane)
     for k in range(Nb):  # C2:506
         if verbose:

@@ -35,8 +35,14 @@ struct Ctx {
   double *d_acc = nullptr;
   void *stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_bytes[3] = {0, 0, 0};
-  void *work = nullptr;   // reusable scratch of lange / potrs (grown on demand)
+  void *work = nullptr;   // reusable scratch of lange / potrs / tile batches (grown on demand)
   size_t work_bytes = 0;
+  // block inverses of the last single tile factored or inverted under a version tag (chol_desc_set_version):
+  // the TRSM tasks of a wave all use the L(k,k) the POTRF task before them produced
+  const void *wc_ptr = nullptr;
+  unsigned long long wc_version = 0;
+  int wc_mb = 0, wc_dtype = 0;
+  void *wc_winv = nullptr;
   std::string last_error;
 };
 Ctx g;
@@ -80,6 +86,37 @@ int ensure_stage(int idx, size_t bytes) {
   HIPCHECK(hipMalloc(&g.stage[idx], bytes));
   g.stage_bytes[idx] = bytes;
   return 0;
+}
+
+int ensure_work(size_t bytes) {
+  if (g.work_bytes >= bytes) return 0;
+  if (g.work) HIPCHECK(hipFree(g.work));
+  g.work = nullptr;
+  g.work_bytes = 0;
+  bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  HIPCHECK(hipMalloc(&g.work, bytes));
+  g.work_bytes = bytes;
+  return 0;
+}
+
+// the cached block inverses for (tile pointer, version), or null
+const void *cached_winv(const void *ptr, unsigned long long version, int mb, int dtype) {
+  if (!version || !g.wc_winv || g.wc_ptr != ptr || g.wc_version != version || g.wc_mb != mb || g.wc_dtype != dtype) return nullptr;
+  return g.wc_winv;
+}
+// remember the block inverses in g.r.winv (first set) for (ptr, version); stream-ordered on ST_MAIN
+int remember_winv(const void *ptr, unsigned long long version, int mb, int dtype, size_t bytes) {
+  if (!version) return 0;
+  if (!g.wc_winv) HIPCHECK(hipMalloc(&g.wc_winv, g.r.winv_bytes));
+  HIPCHECK(hipMemcpyAsync(g.wc_winv, g.r.winv, bytes, hipMemcpyDeviceToDevice, g.r.st[ST_MAIN]));
+  g.wc_ptr = ptr;
+  g.wc_version = version;
+  g.wc_mb = mb;
+  g.wc_dtype = dtype;
+  return 0;
+}
+void forget_winv(const void *ptr) {
+  if (g.wc_ptr == ptr) g.wc_ptr = nullptr, g.wc_version = 0;
 }
 
 int ensure_events(size_t n) {
@@ -226,11 +263,18 @@ static int potrf_impl(chol_desc *A, bool upper_staged = false) {
     launch_potrf_tile<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(st.dev), st.ldp, reinterpret_cast<T *>(g.r.winv),
                          g.r.d_info, 0, tile_sems());
     if (upper_staged) launch_transpose_inplace<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(st.dev), 1, st.ldp);
+    // an in-place device tile with a version tag: its block inverses serve the TRSM tasks that name the same content
+    if (st.in_place && !upper_staged)
+      rc = remember_winv(A->mat, A->version, st.ldp, A->dtype, (size_t)(st.ldp / MACRO) * MACRO * MACRO * sizeof(T));
+    else
+      forget_winv(A->mat);
+    if (rc) return rc;
     rc = stage_out<T>(A, st);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
     int info = 0;
     rc = read_info(&info);
+    if (!rc && info != 0) forget_winv(A->mat);
     return rc ? rc : info;
   }
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "potrf_tile: matrix is not square");
@@ -263,8 +307,19 @@ static int trsm_impl(double alpha, chol_desc *L, chol_desc *B) {
   if (rc) return rc;
   rc = stage_in<T>(B, 1, false, &sb);
   if (rc) return rc;
-  T *winv = reinterpret_cast<T *>(g.r.winv);
-  launch_invert_diag<T>(g.r.st[ST_MAIN], reinterpret_cast<const T *>(sl.dev), sl.ldp, winv);
+  // the block inverses of L: those the POTRF task of the same content left behind (chol_desc_set_version), else
+  // recomputed from the tile (mb/128 diagonal-block launches) and kept under L's tag for the TRSMs that follow
+  const T *winv = sl.in_place ? reinterpret_cast<const T *>(cached_winv(L->mat, L->version, sl.ldp, L->dtype)) : nullptr;
+  if (!winv) {
+    T *w = reinterpret_cast<T *>(g.r.winv);
+    launch_invert_diag<T>(g.r.st[ST_MAIN], reinterpret_cast<const T *>(sl.dev), sl.ldp, w);
+    if (sl.in_place) {
+      rc = remember_winv(L->mat, L->version, sl.ldp, L->dtype, (size_t)(sl.ldp / MACRO) * MACRO * MACRO * sizeof(T));
+      if (rc) return rc;
+    }
+    winv = w;
+  }
+  forget_winv(B->mat);  // (B is overwritten)
   launch_trsm_panel<T>(g.r.st[ST_MAIN], reinterpret_cast<T *>(sb.dev), (long)sb.ldp * sb.ldp, 1,
                        reinterpret_cast<const T *>(sl.dev), winv, sb.ldp, (T)alpha);
   rc = stage_out<T>(B, sb);
@@ -286,6 +341,7 @@ static int gemm_impl(double alpha, chol_desc *A, chol_desc *B, double beta, chol
   }
   rc = stage_in<T>(C, 2, false, &sc);
   if (rc) return rc;
+  forget_winv(C->mat);
   launch_gemm_nt_tile<T>(g.r.st[ST_MAIN], reinterpret_cast<const T *>(sa.dev), reinterpret_cast<const T *>(sb.dev),
                          reinterpret_cast<T *>(sc.dev), sc.ldp, (T)alpha, (T)beta, lower);
   rc = stage_out<T>(C, sc);
@@ -308,11 +364,11 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
   const long bs = A->bsizi;
   const size_t tb = (size_t)bs * sizeof(T);
   T *La = reinterpret_cast<T *>(A->mat), *Bm = reinterpret_cast<T *>(B->mat);
-  T *scr = nullptr;
-  if (hipMalloc(&scr, ((size_t)nr * nt + 2 + (size_t)nr + (size_t)nt) * tb) != hipSuccess) {
+  if (ensure_work(((size_t)nr * nt + 2 + (size_t)nr + (size_t)nt) * tb)) {
     (void)hipGetLastError();
     return fail(CHOL_ERR_OUT_OF_MEMORY, "potrs_tile: scratch allocation failed");
   }
+  T *scr = reinterpret_cast<T *>(g.work);
   T *Z = scr, *Wt = scr + (size_t)nr * nt * bs, *Tt = Wt + bs, *tmp = Tt + (size_t)nt * bs;  // Tt: nt tiles, tmp: nr tiles
   hipStream_t s = g.r.st[ST_MAIN];
   T *winv = reinterpret_cast<T *>(g.r.winv);
@@ -344,9 +400,8 @@ int potrs_impl(chol_desc *A, chol_desc *B) {
   }
   for (int r = 0; r < nr; ++r)  // B(i,r) = Z(r,i)^T
     launch_tiles_transpose<T>(s, Ztile(r, 0), (long)nr * bs, Bm + (long)r * B->lmt * bs, bs, mb, nt);
-  hipError_t e = hipStreamSynchronize(s);
-  (void)hipFree(scr);
-  if (e != hipSuccess) return fail_hip(e, "potrs_tile", __LINE__);
+  HIPCHECK(hipGetLastError());  // (a refused launch configuration must not come back as a wrong solution)
+  HIPCHECK(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -614,6 +669,10 @@ int chol_finalize(void) {
   if (g.work) (void)hipFree(g.work);
   g.work = nullptr;
   g.work_bytes = 0;
+  if (g.wc_winv) (void)hipFree(g.wc_winv);
+  g.wc_winv = nullptr;
+  g.wc_ptr = nullptr;
+  g.wc_version = 0;
   (void)hipFree(g.d_acc);
   if (g.d_ytab) (void)hipFree(g.d_ytab);
   g.d_ytab = nullptr;
@@ -685,10 +744,10 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
   if ((multi && (lm % mb || ln % nb || mb % MACRO)) || partial1) {
     // ragged order and/or a tile edge that is not a multiple of 128 (the reference's sweep
     // uses NB = 192 ... 448): the library keeps its own image with tiles rounded up to 128
-    // and the identity outside the matrix.  Needs library-owned storage on one process.
-    if (mat || p * q != 1 || mb != nb)
+    // and the identity outside the matrix.  Needs library-owned storage (each rank of a p x q grid its own).
+    if (mat || mb != nb)
       return delete d, fail(CHOL_ERR_NOT_SUPPORTED,
-                            "desc_create: ragged / non-128 tiles need mat == NULL, p*q == 1, square tiles");
+                            "desc_create: ragged / non-128 tiles need mat == NULL and square tiles");
     d->mbi = roundup(mb, MACRO);
     d->bsizi = d->mbi * d->mbi;
     d->padded = true;
@@ -712,9 +771,9 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
     if (d->padded && lm == ln) {  // zero everywhere, identity on the diagonal tiles' diagonals
       const LocalMat Lm = local_mat(d, d->mat);
       if (dtype == CHOL_REAL_DOUBLE)
-        launch_plgsy<double>(g.r.st[ST_MAIN], Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
+        launch_plgsy<double>(g.r.st[ST_MAIN], Lm, d->lnt, d->prow, d->pcol, 0.0, 0ull, 0, 0, 0);
       else
-        launch_plgsy<float>(g.r.st[ST_MAIN], Lm, d->lnt, 0, 0, 0.0, 0ull, 0, 0, 0);
+        launch_plgsy<float>(g.r.st[ST_MAIN], Lm, d->lnt, d->prow, d->pcol, 0.0, 0ull, 0, 0, 0);
       (void)hipStreamSynchronize(g.r.st[ST_MAIN]);
     } else {  // library-owned storage starts at zero (tiles a one-sided dplgsy does not touch)
       (void)hipMemsetAsync(d->mat, 0, bytes, g.r.st[ST_MAIN]);
@@ -736,6 +795,7 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
 int chol_desc_destroy(chol_desc_t **desc) {
   if (!desc || !*desc) return fail(-1, "desc_destroy: NULL");
   chol_desc *d = *desc;
+  if (d->owns) forget_winv(d->mat);
   if (d->d_list) (void)hipFree(d->d_list);
   if (d->owns && d->mat) (void)hipFree(d->mat);
   delete d;
@@ -753,6 +813,83 @@ int chol_desc_local_tiles(chol_desc_t *d, int *lmt, int *lnt) {
   if (!d) return fail(-1, "NULL desc");
   if (lmt) *lmt = d->lmt;
   if (lnt) *lnt = d->lnt;
+  return 0;
+}
+
+int chol_desc_set_version(chol_desc_t *d, unsigned long long version) {
+  if (!d) return fail(-1, "desc_set_version: NULL descriptor");
+  d->version = version;
+  return 0;
+}
+
+int chol_sync(void) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "chol_sync before chol_init");
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- the tasks of one op class in one grouped launch
+template <typename T>
+static int tile_batch_impl(int op, int mb, int n, const void *const *c_in, const void *const *a, const void *const *b,
+                           void *const *c_out) {
+  hipStream_t s = g.r.st[ST_MAIN];
+  const size_t tb = (size_t)mb * mb * sizeof(T);
+  // device copies of the four pointer lists (stream-ordered behind the kernels still reading the last batch's)
+  const size_t lb = (size_t)n * sizeof(void *);
+  int rc = ensure_stage(0, 4 * lb);
+  if (rc) return rc;
+  char *dl = reinterpret_cast<char *>(g.stage[0]);
+  const void *const *lists[4] = {c_in, a, b ? b : a, (const void *const *)c_out};
+  std::vector<const void *> packed((size_t)4 * n);
+  for (int l = 0; l < 4; ++l) memcpy(packed.data() + (size_t)l * n, lists[l], lb);
+  HIPCHECK(hipMemcpyAsync(dl, packed.data(), 4 * lb, hipMemcpyHostToDevice, s));
+  const void *const *d_cin = (const void *const *)dl, *const *d_a = (const void *const *)(dl + lb),
+                    *const *d_b = (const void *const *)(dl + 2 * lb);
+  void *const *d_out = (void *const *)(dl + 3 * lb);
+  // the private copy of the tile each task updates (W2:212-213), for all tasks in one launch
+  launch_copy_ptrs(s, d_cin, d_out, n, (long)tb);
+  for (int t = 0; t < n; ++t) forget_winv(c_out[t]);
+  if (op == CHOL_BATCH_GEMM || op == CHOL_BATCH_SYRK) {
+    launch_gemm_nt_ptrs<T>(s, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, T(-1), T(1),
+                           op == CHOL_BATCH_SYRK);
+  } else {  // TRSM: runs of consecutive tasks with the same L and outputs laid out back to back go out as panels
+    int t0 = 0;
+    while (t0 < n) {
+      int t1 = t0 + 1;
+      while (t1 < n && a[t1] == a[t0] && (const char *)c_out[t1] == (const char *)c_out[t1 - 1] + tb) ++t1;
+      // (at most g_trsm_small_max / nbm tiles per launch: the small-block kernels of the one-tile call, same bits)
+      const int per = std::max(1, cholmi::g_trsm_small_max / (mb / MACRO));
+      const T *L = reinterpret_cast<const T *>(a[t0]);
+      T *w = reinterpret_cast<T *>(g.r.winv);
+      launch_invert_diag<T>(s, L, mb, w);
+      for (int q = t0; q < t1; q += per)
+        launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[q]), (long)mb * mb, std::min(per, t1 - q), L, w, mb, T(1));
+      t0 = t1;
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
+                    const void *const *b, void *const *c_out, int flags) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "tile_batch before chol_init");
+  if (op != CHOL_BATCH_TRSM && op != CHOL_BATCH_SYRK && op != CHOL_BATCH_GEMM) return fail(-1, "tile_batch: op");
+  if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-2, "tile_batch: dtype");
+  if (mb <= 0 || mb % MACRO || mb > 4096) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_batch: tile edge must be a multiple of 128, at most 4096");
+  if (n < 0) return fail(-4, "tile_batch: n");
+  if (n == 0) return 0;
+  if (!c_in || !a || !c_out || (op == CHOL_BATCH_GEMM && !b)) return fail(-5, "tile_batch: NULL pointer list");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, mb, n, c_in, a, b, c_out)
+                                           : tile_batch_impl<float>(op, mb, n, c_in, a, b, c_out);
+  if (rc) return rc;
+  if (!(flags & CHOL_BATCH_ASYNC)) HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
 
@@ -932,8 +1069,9 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
   if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   const TileGeo ge = geo_of(A);
-  double *work = nullptr;
-  HIPCHECK(hipMalloc(&work, (size_t)(std::max(ge.m, ge.n) + 2) * sizeof(double)));
+  int rcw = ensure_work((size_t)(std::max(ge.m, ge.n) + 2) * sizeof(double));
+  if (rcw) return rcw;
+  double *work = reinterpret_cast<double *>(g.work);
   if (A->dtype == CHOL_REAL_DOUBLE)
     launch_lange<double>(g.r.st[ST_MAIN], ge, kind, (const double *)A->mat, work);
   else
@@ -941,7 +1079,6 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
   double v = 0;
   hipError_t e = hipMemcpyAsync(&v, work, sizeof(double), hipMemcpyDeviceToHost, g.r.st[ST_MAIN]);
   if (e == hipSuccess) e = hipStreamSynchronize(g.r.st[ST_MAIN]);
-  (void)hipFree(work);
   if (e != hipSuccess) return fail_hip(e, "lange_tile", __LINE__);
   *value = kind == 3 ? std::sqrt(v) : v;
   return 0;
@@ -982,7 +1119,7 @@ int chol_lauum_tile(int uplo, chol_desc_t *A) {
 // ---------------------------------------------------------------- solve with the factor
 int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrs_tile before chol_init");
-  if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: only ChamLower");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrs_tile: uplo");
   int rc = resident_whole("potrs_tile", A);
   if (rc) return rc;
   rc = resident_whole("potrs_tile", B);
@@ -993,11 +1130,25 @@ int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
   if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: stored tile edge must be a multiple of 64");
   CHECK_WINV(A, "potrs_tile");
   std::lock_guard<std::mutex> lk(g_mu);
-  return A->dtype == CHOL_REAL_DOUBLE ? potrs_impl<double>(A, B) : potrs_impl<float>(A, B);
+  // ChamUpper: A = U^T U with U = L^T -- transpose the factor's storage in place around the Lower solve
+  // (as chol_potrf_tile does around the Lower factorisation); the strict lower triangle comes back as it was
+  auto flip = [&]() {
+    if (A->dtype == CHOL_REAL_DOUBLE)
+      launch_transpose_inplace<double>(g.r.st[ST_MAIN], (double *)A->mat, A->nt, A->mbi);
+    else
+      launch_transpose_inplace<float>(g.r.st[ST_MAIN], (float *)A->mat, A->nt, A->mbi);
+  };
+  if (uplo == CHOL_UPPER) flip();
+  rc = A->dtype == CHOL_REAL_DOUBLE ? potrs_impl<double>(A, B) : potrs_impl<float>(A, B);
+  if (uplo == CHOL_UPPER) {
+    flip();
+    HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  }
+  return rc;
 }
 
 int chol_posv_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
-  if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "posv_tile: only ChamLower");
+  if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "posv_tile: uplo");
   const int info = chol_potrf_tile(uplo, A);
   if (info != 0) return info;  // > 0: not positive definite, B untouched (LAPACK dposv)
   return chol_potrs_tile(uplo, A, B);

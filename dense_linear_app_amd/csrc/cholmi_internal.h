@@ -27,6 +27,9 @@ struct chol_desc {
   int2 *d_list = nullptr;
   std::vector<int> ge, gd;
   int n_off = 0;
+  // chol_desc_set_version: names the CONTENT behind `mat` (the worker: a hash of the write-once result id the
+  // blob belongs to); lets the library keep the block inverses of a factored tile for the TRSM tasks that follow
+  unsigned long long version = 0;
 };
 
 extern "C" int chol_internal_fail(int code, const char *msg);  // api.hip: sets chol_last_error, returns code
@@ -191,6 +194,13 @@ void launch_gemm_nt_tile(hipStream_t s, const T *A, const T *B, T *C, int mb, T 
 template <typename T>
 void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *B, long sB, int nz2, T *C, long sC1,
                           long sC2, int mb, T alpha, T beta);
+
+// the same product for n (A[z], B[z], C[z]) triples given as device arrays of device pointers, C in place
+template <typename T>
+void launch_gemm_nt_ptrs(hipStream_t s, const T *const *A, const T *const *B, T *const *C, int n, int mb, T alpha, T beta,
+                         bool lower_only);
+// dst[z] <- src[z], z < n, `bytes` (a multiple of 16) each; src / dst: device arrays of device pointers
+void launch_copy_ptrs(hipStream_t s, const void *const *src, void *const *dst, int n, long bytes);
 
 template <typename T>
 void launch_plgsy(hipStream_t s, const LocalMat &A, int lnt, int prow, int pcol, double bump,

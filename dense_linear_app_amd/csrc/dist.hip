@@ -437,6 +437,15 @@ int hub_allreduce_max(void *ctx, long long *value) {
   return 0;
 }
 
+// ---------------------------------------------------------------- null transport (timing one rank alone)
+int null_group(void *) { return 0; }
+int null_send(void *, const void *, size_t, int, void *) { return 0; }
+int null_recv(void *, void *buf, size_t bytes, int, void *stream) {
+  HIPRC(hipMemsetAsync(buf, 0, bytes, (hipStream_t)stream));  // zeros: every update subtracts nothing, every tile stays finite
+  return 0;
+}
+int null_allreduce(void *, long long *) { return 0; }
+
 // ---------------------------------------------------------------- running the walker
 WaveCalib calib_for(const RankCtx *r, int dtype, const WaveGeo &g) {
   const int idx = dtype == CHOL_REAL_DOUBLE ? 0 : 1;
@@ -535,6 +544,20 @@ int chol_set_transport(const chol_transport_t *t) {
   g_tr[0] = g_tr[1] = *t;
   g_tr_set = true;
   return 0;
+}
+
+// Test hook: a transport that moves nothing -- sends vanish, receives deliver zeros (stream-ordered).  One process
+// can then play ANY single rank of a p x q grid on a one-GPU box and time that rank's real schedule with
+// communication taken as free (scripts/dist_issue_time.py; the projection in DESIGN.md section 5).
+int chol_set_transport_null(void) {
+  chol_transport_t t;
+  t.ctx = nullptr;
+  t.group_begin = null_group;
+  t.send = null_send;
+  t.recv = null_recv;
+  t.group_end = null_group;
+  t.allreduce_max = null_allreduce;
+  return chol_set_transport(&t);
 }
 
 int chol_transport_rccl_unique_id(void *id256) {
@@ -732,17 +755,18 @@ int chol_dist_rehearse(int dtype, int N, int mb, int p, int q, double bump, unsi
   if (!mr->st[ST_MAIN]) return chol_internal_fail(CHOL_ERR_NOT_INITIALIZED, "dist_rehearse before chol_init");
   const int R = p * q;
   if (p < 1 || q < 1 || p > MAXP || R > 16) return chol_internal_fail(-4, "dist_rehearse: grid");
-  if (N <= 0 || mb <= 0 || N % mb || mb % MACRO) return chol_internal_fail(-2, "dist_rehearse: N must be a multiple of mb, mb of 128");
-  if (!full || full->p * full->q != 1 || full->lm != N || full->mbi != mb || full->dtype != dtype || !full->on_device)
+  if (N <= 0 || mb <= 0) return chol_internal_fail(-2, "dist_rehearse: N, mb");
+  if (!full || full->p * full->q != 1 || full->lm != N || full->mb != mb || full->dtype != dtype || !full->on_device)
     return chol_internal_fail(-8, "dist_rehearse: `full` must be a device-resident 1 x 1 descriptor of order N, tile mb, same type");
+  const int mbi = full->mbi;  // stored tile edge (mb rounded up to 128 when N is ragged or mb no multiple of 128)
   std::vector<RankCtx> ctx(R);
   std::vector<chol_desc_t *> desc(R, nullptr);
   std::vector<HubEnd> ends(2 * R);
   Hub hub;
   hub.nranks = R;
   int rc = 0;
-  const int nt = N / mb;
-  const size_t tb = (size_t)mb * mb * (dtype == CHOL_REAL_DOUBLE ? 8 : 4);
+  const int nt = (N + mb - 1) / mb;
+  const size_t tb = (size_t)mbi * mbi * (dtype == CHOL_REAL_DOUBLE ? 8 : 4);
   // staging for everything that is ever sent: every panel tile to at most p + q - 2 peers, plus diagonal and head tiles
   hub.arena_bytes = (size_t)nt * (nt + 1) / 2 * tb * (size_t)std::max(1, p + q - 2) + (size_t)4 * nt * p * tb + (64u << 20);
   if (hipMalloc(&hub.arena, hub.arena_bytes) != hipSuccess) {

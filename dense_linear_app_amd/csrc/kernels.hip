@@ -1461,6 +1461,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A
                  lower && mi == mj);
 }
 
+// The same product for a LIST of tile triples (the tasks of one op class of a wave of the worker path,
+// chol_tile_batch): task z = blockIdx.z reads A[z], B[z] and updates C[z] in place -- the arithmetic of
+// k_gemm_nt_tile, block for block, so a batch gives the bits the one-tile calls give.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_ptrs(const T *const *__restrict__ Ap, const T *const *__restrict__ Bp,
+                                                         T *const *__restrict__ Cp, int mb, int nbm, T alpha, T beta,
+                                                         int lower) {
+  __shared__ SmemP<T> sm;
+  const int mi = blockIdx.x, mj = blockIdx.y;
+  if (lower && mi < mj) return;
+  const T *A = Ap[blockIdx.z], *B = Bp[blockIdx.z];
+  T *C = Cp[blockIdx.z];
+  Acc<T> acc;
+  acc_zero<T>(acc);
+  nt_kloop_paired<T, true>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
+  nt_epilogue_paired<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta, lower && mi == mj);
+}
+// dst[z] <- src[z], `bytes` (a multiple of 16) each: the private copies the worker makes of the tiles it updates
+__global__ __launch_bounds__(256) void k_copy_ptrs(const void *const *__restrict__ src, void *const *__restrict__ dst, long bytes) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(src[blockIdx.y]);
+  uint4 *d = reinterpret_cast<uint4 *>(dst[blockIdx.y]);
+  const long n = bytes / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // ------------------------------------------------------------------------------
 // 128 x 128 diagonal block: lower Cholesky and the inverse of the triangular factor,
 // one 256-thread workgroup, the block resident in LDS.
@@ -2662,8 +2687,42 @@ template <typename T>
 void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *B, long sB, int nz2, T *C, long sC1,
                           long sC2, int mb, T alpha, T beta) {
   const int nbm = mb / MACRO;
-  if (nz1 > 0 && nz2 > 0)
-    k_gemm_nt_tile<T><<<dim3(nbm, nbm, nz1 * nz2), 256, 0, s>>>(A, B, C, mb, nbm, alpha, beta, 0, nz1, sA, sB, sC1, sC2);
+  if (nz1 <= 0 || nz2 <= 0) return;
+  // grid.z is a 16-bit quantity: whole z2-slices per launch (z = z1 + nz1 z2), a single slice in pieces of z1
+  if (nz1 <= 65535) {
+    const int per = std::max(1, 65535 / nz1);
+    for (int z2 = 0; z2 < nz2; z2 += per) {
+      const int c = std::min(per, nz2 - z2);
+      k_gemm_nt_tile<T><<<dim3(nbm, nbm, nz1 * c), 256, 0, s>>>(A, B + (long)z2 * sB, C + (long)z2 * sC2, mb, nbm, alpha, beta, 0,
+                                                               nz1, sA, sB, sC1, sC2);
+    }
+  } else {
+    for (int z2 = 0; z2 < nz2; ++z2)
+      for (int z1 = 0; z1 < nz1; z1 += 65535) {
+        const int c = std::min(65535, nz1 - z1);
+        k_gemm_nt_tile<T><<<dim3(nbm, nbm, c), 256, 0, s>>>(A + (long)z1 * sA, B + (long)z2 * sB, C + (long)z1 * sC1 + (long)z2 * sC2,
+                                                          mb, nbm, alpha, beta, 0, c, sA, sB, sC1, sC2);
+      }
+  }
+}
+
+template <typename T>
+void launch_gemm_nt_ptrs(hipStream_t s, const T *const *A, const T *const *B, T *const *C, int n, int mb, T alpha, T beta,
+                         bool lower_only) {
+  const int nbm = mb / MACRO;
+  for (int z0 = 0; z0 < n; z0 += 65535) {  // grid.z is a 16-bit quantity
+    const int nz = std::min(65535, n - z0);
+    k_gemm_nt_ptrs<T><<<dim3(nbm, nbm, nz), 256, 0, s>>>(A + z0, B + z0, C + z0, mb, nbm, alpha, beta, lower_only ? 1 : 0);
+  }
+}
+template void launch_gemm_nt_ptrs<double>(hipStream_t, const double *const *, const double *const *, double *const *, int, int, double, double, bool);
+template void launch_gemm_nt_ptrs<float>(hipStream_t, const float *const *, const float *const *, float *const *, int, int, float, float, bool);
+
+void launch_copy_ptrs(hipStream_t s, const void *const *src, void *const *dst, int n, long bytes) {
+  for (int z0 = 0; z0 < n; z0 += 65535) {
+    const int nz = std::min(65535, n - z0);
+    k_copy_ptrs<<<dim3((unsigned)std::max(1L, std::min(64L, bytes / (16 * 256 * 4))), nz), 256, 0, s>>>(src + z0, dst + z0, bytes);
+  }
 }
 
 template <typename T>

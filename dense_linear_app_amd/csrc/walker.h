@@ -93,7 +93,11 @@ struct WaveSwitches {
   int pair_max_mb = 1024;
   double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, halves_max_rounds = 24.0;
   bool syrk_pipe = true, split_always = false, head_first = true;
+  // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
+  // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
+  int pair_start = 1;
   WaveSwitches() {
+    if (const char *e = getenv("CHOLMI_PAIR_START")) pair_start = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_PAIR_MAX_MB")) pair_max_mb = atoi(e);
     if (const char *e = getenv("CHOLMI_PAIR_FACTOR")) pair_fac = atof(e);
     if (const char *e = getenv("CHOLMI_YIELD_FACTOR")) yfac = atof(e);
@@ -342,7 +346,8 @@ struct Walker {
       // ST_PANEL behind the first diagonal-block step, and a record on ST_PANEL costs the chain ~7 us)
       if (k > 0 && in_col) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
       const int local_tiles = g.tiles_in(k + 1, nt);  // this rank's tiles of wave k's update
-      if ((k & 1) == 0)
+      const bool pair_first = k >= sw.pair_start && ((k - sw.pair_start) & 1) == 0;
+      if (pair_first)
         paired = mb <= sw.pair_max_mb && k + 2 < nt && (double)local_tiles * t_tile >= sw.pair_fac * t_panel;
       // Plain (unpaired) wave whose panel chain is (nearly) critical: the SYRK on tile (k+1,k+1) follows the
       // head tile's TRSM steps slice by slice and the chain's cross-stream edges are device-side counters
@@ -424,7 +429,13 @@ struct Walker {
         // Every column is written by launches of ST_U1 in program order, except by big(); the first launches
         // of ST_U1 on a column big(k) covers are Ca / Cb of wave k+2, which wait for it.  POTRF(k+1) waits
         // for the SYRKs on (k+1,k+1) only, TRSM(k+1) for the rest of column k+1.
-        const bool odd = (k & 1) != 0;
+        const bool odd = !pair_first;
+        // the first pair behind plain waves: their far launch (ST_MAIN) wrote the columns ST_U1 is about to touch
+        if (!odd && k > 0 && !had_pairs) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));
+        if (prev_halves) {  // ... and their near launch (ST_U1) the columns ST_MAIN is about to touch
+          WRC(o.wt(ST_MAIN, ev(k - 1, E_NEAR)));
+          prev_halves = false;
+        }
         const PanelRef &prev = pan[(odd ? k - 1 : k) % NBUF];
         const PanelRef *p2 = odd ? &pk : nullptr;  // launches: first `prev`, then `pk` when odd
         const PanelRef &p1 = odd ? prev : pk;
@@ -456,7 +467,6 @@ struct Walker {
           if (n_cb > 0) ++timed, fl += 2.0 * g.off_in(k + 3, k + 4) + g.diag_in(k + 3, k + 4);
           WRC(o.rec(fx(F_COLS), ST_U1));
           cols_pending = true;
-          had_pairs = true;
           WRC(o.wt(ST_MAIN, ev(k, E_PANEL)));
           if (prof) WRC(o.rec(ev(k, E_P0), ST_MAIN));
           WRC(o.update(k1, k2, k + 4, nt, 3, p1, p2, yield, ST_MAIN));
@@ -486,6 +496,7 @@ struct Walker {
           open_bracket = -1;
           if (o_c1 > 0) ++upd_launches, upd_flops += 2.0 * o_c1 * b3;
         }
+        had_pairs = true;
         if (mr) WRC(o.rec(ev(k, E_SU), ST_U1));
         continue;
       }

@@ -160,6 +160,9 @@ class TorchTransport:
         return 0
 
     def _send(self, ctx, buf, nbytes, peer, stream):
+        if getattr(self, "trace", False):
+            print(f"[transport {self.dist.get_rank()}] send {nbytes} B -> {peer}", flush=True)
+
         def f():
             t = self._view(buf, nbytes)
             self.keep.append(t)
@@ -168,6 +171,9 @@ class TorchTransport:
         return self._guard(f)
 
     def _recv(self, ctx, buf, nbytes, peer, stream):
+        if getattr(self, "trace", False):
+            print(f"[transport {self.dist.get_rank()}] recv {nbytes} B <- {peer}", flush=True)
+
         def f():
             t = self._view(buf, nbytes)
             self.keep.append(t)
@@ -175,6 +181,9 @@ class TorchTransport:
         return self._guard(f)
 
     def _end(self, ctx):
+        if getattr(self, "trace", False):
+            print(f"[transport {self.dist.get_rank()}] group of {len(self.ops)} ends", flush=True)
+
         def f():
             if self.device is not None:
                 self.torch.cuda.synchronize(self.device)
@@ -185,11 +194,24 @@ class TorchTransport:
                 ops = [self.dist.P2POp(self.dist.isend if kind == "s" else self.dist.irecv, t, peer, self.group)
                        for kind, t, peer in self.ops]
                 reqs = self.dist.batch_isend_irecv(ops)
+                for r in reqs:
+                    r.wait()
             else:
-                reqs = [self.dist.isend(t, peer, group=self.group) if kind == "s" else
-                        self.dist.irecv(t, peer, group=self.group) for kind, t, peer in self.ops]
-            for r in reqs:
-                r.wait()
+                # gloo moves HOST memory: device tiles are staged through host tensors (handing gloo a device
+                # pointer happens to work through the PCIe BAR mapping, and hangs now and then)
+                staged = []
+                reqs = []
+                for kind, t, peer in self.ops:
+                    h = t if self.device is None else (t.cpu() if kind == "s" else self.torch.empty(t.numel(), dtype=self.torch.uint8))
+                    staged.append((kind, t, h))
+                    reqs.append(self.dist.isend(h, peer, group=self.group) if kind == "s" else
+                                self.dist.irecv(h, peer, group=self.group))
+                for r in reqs:
+                    r.wait()
+                if self.device is not None:
+                    for kind, t, h in staged:
+                        if kind == "r":
+                            t.copy_(h)
             if self.device is not None:
                 self.torch.cuda.synchronize(self.device)
             self.ops, self.keep = [], []

@@ -251,10 +251,15 @@ def v3_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr) -> int:
         err.write("Warning: bump==0 -> matrix may not be SPD.\n")
     mat = None
     if vals["mat"] not in ("none", "NULL", "0"):
+        # a user buffer in tile layout (v3:205-212): whole tiles only, and -- this library -- no sub-matrix view
+        if lm % mb or ln % nb:
+            err.write(f"Error: --mat user needs lm, ln multiples of mb, nb (lm={lm} ln={ln} mb={mb} nb={nb}).\n")
+            return 1
         mat = np.zeros(lm * ln, dtype=np.float64 if dtyp == ch.ChamRealDouble else np.float32)
     ch.CHAMELEON_Init(ncpu, ngpu)
     try:
-        descA = ch.CHAMELEON_Desc_Create(mat, dtyp, mb, nb, mb * nb, lm, ln, ioff, joff, m, n, p, q)
+        # bsiz goes straight through, as in the reference (v3:212); the library refuses bsiz != mb*nb with its own message
+        descA = ch.CHAMELEON_Desc_Create(mat, dtyp, mb, nb, bsiz, lm, ln, ioff, joff, m, n, p, q)
         if mat is None:
             ch.CHAMELEON_dplgsy_Tile(bump, uplo, descA, seed)
         else:  # the generator runs on the device: fill a resident twin, bring the tiles to the host buffer
@@ -268,7 +273,7 @@ def v3_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr) -> int:
         t0 = time.perf_counter()
         info = ch.CHAMELEON_dpotrf_Tile(uplo, descA)
         time_sec = time.perf_counter() - t0
-    except ch.CholmiError as e:
+    except (ch.CholmiError, ValueError) as e:
         err.write(f"Error: {e}\n")
         return 1
     dim = float(min(m, n))

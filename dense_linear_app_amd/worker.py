@@ -80,19 +80,35 @@ def create_desc_1block(buf: np.ndarray, B: int) -> ch.Desc:
     return ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, B, B, B * B, B, B, 0, 0, B, B, 1, 1)
 
 
-class HipTileBackend:
-    """The four tile routines on 1-tile descriptors, through the C ABI (no fallback)."""
+def _tag_of(result_id: Optional[str]) -> int:
+    """64-bit name of a write-once result's content (chol_desc_set_version); 0 = unnamed."""
+    if not result_id:
+        return 0
+    import zlib
 
-    def potrf(self, A: np.ndarray, B: int) -> int:
+    b = result_id.encode()
+    return ((zlib.crc32(b) << 32) | zlib.adler32(b)) or 1
+
+
+class HipTileBackend:
+    """The four tile routines on 1-tile descriptors, through the C ABI (no fallback).
+    `tag`: the write-once result id a device tile belongs to; lets the library keep L(k,k)'s block inverses
+    from the POTRF task for the TRSM tasks of the same wave (chol_desc_set_version)."""
+
+    def potrf(self, A: np.ndarray, B: int, tag: Optional[str] = None) -> int:
         d = create_desc_1block(A, B)
         try:
+            if tag:
+                d.set_version(_tag_of(tag))
             return ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)  # W2:238
         finally:
             ch.CHAMELEON_Desc_Destroy(d)  # W2:256
 
-    def trsm(self, L: np.ndarray, A: np.ndarray, B: int) -> int:
+    def trsm(self, L: np.ndarray, A: np.ndarray, B: int, tag: Optional[str] = None) -> int:
         dL, dA = create_desc_1block(L, B), create_desc_1block(A, B)
         try:
+            if tag:
+                dL.set_version(_tag_of(tag))
             return ch.CHAMELEON_dtrsm_Tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, dL, dA)  # W2:323
         finally:
             ch.CHAMELEON_Desc_Destroy(dL)
@@ -137,11 +153,26 @@ class _DevTile:
         return np.frombuffer(self.t.cpu().numpy().tobytes(), dtype=np.float64)
 
 
-def _to_doubles(blob):
+class _DevView:
+    """A device tile blob used as a READ-ONLY operand: no private copy (results are write-once, and the library
+    never writes its A / L operands)."""
+
+    def __init__(self, blob: DeviceBlob):
+        self.t = blob.tensor
+        self.size = blob.nbytes // 8
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def host(self) -> np.ndarray:
+        return np.frombuffer(self.t.cpu().numpy().tobytes(), dtype=np.float64)
+
+
+def _to_doubles(blob, readonly: bool = False):
     """bytes -> std::vector<double> (full copy, W2:212-213); trailing partial doubles dropped.
-    A DeviceBlob is copied device-to-device and never leaves HBM."""
+    A DeviceBlob is copied device-to-device and never leaves HBM; read-only operands are not copied at all."""
     if isinstance(blob, DeviceBlob):
-        return _DevTile(blob)
+        return _DevView(blob) if readonly else _DevTile(blob)
     n = len(blob) // 8
     return np.frombuffer(blob, dtype=np.float64, count=n).copy()
 
@@ -154,6 +185,9 @@ class DagCholeskyWorker(ArmoniKWorker):
         self.verbose = verbose
         self.log = log or sys.stdout
         self.last_perf: Optional[dict] = None  # op, secs, flops, gflops of the last task (W2:246-248)
+        self._tags = isinstance(self.backend, HipTileBackend)
+        self.batches = 0        # grouped launches issued by ExecuteBatch
+        self.batched_tasks = 0  # tasks they covered
 
     # -- diagnostics of W2:120-148 (opt-in)
     def _diag(self, tag: str, **arrays):
@@ -161,7 +195,7 @@ class DagCholeskyWorker(ArmoniKWorker):
             return
         parts = []
         for name, X in arrays.items():
-            X = X.host() if isinstance(X, _DevTile) else X
+            X = X.host() if isinstance(X, (_DevTile, _DevView)) else X
             parts.append(f"||{name}||F={np.linalg.norm(X):.6g} NaN/Inf {name}={int((~np.isfinite(X)).sum())}")
         print(f"[WORKER][{tag}] " + " / ".join(parts), file=self.log)
 
@@ -205,7 +239,7 @@ class DagCholeskyWorker(ArmoniKWorker):
                     Ah = A.host() if isinstance(A, _DevTile) else A
                     print(f"[WORKER][POTRF] diag min={Ah[::B + 1].min()}", file=self.log)
                 t0 = time.perf_counter()
-                info = self.backend.potrf(A, B)
+                info = self.backend.potrf(A, B, out_id) if isinstance(A, _DevTile) and self._tags else self.backend.potrf(A, B)
                 secs = time.perf_counter() - t0
                 if info != 0:
                     raise RuntimeError("[Worker][POTF] dpotrf info=" + str(info))
@@ -220,14 +254,14 @@ class DagCholeskyWorker(ArmoniKWorker):
                     return ProcessStatus("[Worker][TRSM] Missing dependency: " + p.inL)
                 if p.inA not in deps:
                     return ProcessStatus("[Worker][TRSM] Missing dependency: " + p.inA)
-                L, A = _to_doubles(deps[p.inL]), _to_doubles(deps[p.inA])
+                L, A = _to_doubles(deps[p.inL], readonly=True), _to_doubles(deps[p.inA])
                 for arr in (L, A):
                     st = bad_size("TRSM", arr)
                     if st:
                         return st
                 self._diag("TRSM", L=L, A0=A)
                 t0 = time.perf_counter()
-                info = self.backend.trsm(L, A, B)
+                info = self.backend.trsm(L, A, B, p.inL) if isinstance(L, _DevView) and self._tags else self.backend.trsm(L, A, B)
                 secs = time.perf_counter() - t0
                 if info != 0:
                     raise RuntimeError("[Worker][TRSM] dtrsm info=" + str(info))
@@ -243,7 +277,7 @@ class DagCholeskyWorker(ArmoniKWorker):
                     return ProcessStatus(" [Worker][SYRK]Missing dependency: " + p.inC)  # sic, W2:370
                 if p.inA not in deps:
                     return ProcessStatus("[Worker][SYRK] Missing dependency: " + p.inA)
-                Cm, A = _to_doubles(deps[p.inC]), _to_doubles(deps[p.inA])
+                Cm, A = _to_doubles(deps[p.inC]), _to_doubles(deps[p.inA], readonly=True)
                 for arr in (Cm, A):
                     st = bad_size("SYRK", arr)
                     if st:
@@ -268,7 +302,8 @@ class DagCholeskyWorker(ArmoniKWorker):
                     return ProcessStatus("[Worker][GEMM] Missing dependency: " + p.inAi)
                 if p.inAj not in deps:
                     return ProcessStatus("[Worker][GEMM] Missing dependency: " + p.inAj)
-                Cm, Ai, Aj = _to_doubles(deps[p.inC]), _to_doubles(deps[p.inAi]), _to_doubles(deps[p.inAj])
+                Cm, Ai, Aj = (_to_doubles(deps[p.inC]), _to_doubles(deps[p.inAi], readonly=True),
+                              _to_doubles(deps[p.inAj], readonly=True))
                 for arr in (Cm, Ai, Aj):
                     st = bad_size("GEMM", arr)
                     if st:
@@ -287,6 +322,78 @@ class DagCholeskyWorker(ArmoniKWorker):
                 return ProcessStatus("Unknown op=" + p.op)  # W2:547-549
         except Exception as e:  # W2:558-560
             return ProcessStatus("Exception: " + str(e))
+
+
+    # ---------------------------------------------------------------- a whole op class of a wave at once
+    _BATCH_OP = {"TRSM": 1, "SYRK": 2, "GEMM": 3}  # include/cholmi.h: CHOL_BATCH_*
+
+    def ExecuteBatch(self, handlers) -> list:  # noqa: N802, C901
+        """every ready task of a wave handed over together.  Same payloads, same checks and the same
+        ProcessStatus per task as Execute; the TRSM / SYRK / GEMM tasks whose tiles are HBM-resident (DeviceBlob)
+        are issued as ONE grouped launch per op class (chol_tile_batch: bit-identical to the one-tile calls),
+        asynchronously -- their results are device blobs ordered on the library's stream.  Everything else
+        (POTRF, host blobs, any task that fails a check) goes through Execute."""
+        import ctypes as C
+
+        import torch
+
+        from ._lib import lib
+
+        n = len(handlers)
+        out: list = [None] * n
+        if not isinstance(self.backend, HipTileBackend):
+            return [self.Execute(h) for h in handlers]
+        groups: dict = {}
+        for idx, h in enumerate(handlers):
+            try:
+                p = handle_json(h.getPayload())
+                code = self._BATCH_OP.get(p.op)
+                if code is None or p.B <= 0 or p.B % 128:
+                    out[idx] = self.Execute(h)
+                    continue
+                names = (p.inA, p.inL) if code == 1 else (p.inC, p.inA) if code == 2 else (p.inC, p.inAi, p.inAj)
+                deps = h.getDataDependencies()
+                blobs = [deps.get(x) for x in names]
+                want = p.B * p.B * 8
+                if any(not isinstance(b, DeviceBlob) or b.nbytes != want for b in blobs):
+                    out[idx] = self.Execute(h)  # (missing / short / host blobs: the per-task path reports them)
+                    continue
+                groups.setdefault((code, p.B), []).append((idx, h, blobs))
+            except Exception as e:  # W2:558-560
+                out[idx] = ProcessStatus("Exception: " + str(e))
+        if groups:
+            torch.cuda.current_stream().synchronize()  # uploads made through torch are visible to the library's stream
+        for (code, B), items in groups.items():
+            m = len(items)
+            res = torch.empty(m * B * B, dtype=torch.float64, device=items[0][2][0].tensor.device)
+            base, tb = res.data_ptr(), B * B * 8
+            ptr = np.empty((4, m), dtype=np.uint64)
+            for q, (_, _, blobs) in enumerate(items):
+                ptr[0, q] = blobs[0].tensor.data_ptr()
+                ptr[1, q] = blobs[1].tensor.data_ptr()
+                ptr[2, q] = blobs[2].tensor.data_ptr() if code == 3 else 0
+            ptr[3, :] = base + tb * np.arange(m, dtype=np.uint64)
+            if code == 1:  # panels: the tasks that share an L side by side
+                order = np.argsort(ptr[1], kind="stable")
+                ptr[:3] = ptr[:3, order]
+                items = [items[int(o)] for o in order]
+            t0 = time.perf_counter()
+            rc = lib().chol_tile_batch(code, ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[1].ctypes.data,
+                                       ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data, 1)
+            self.batches += 1
+            self.batched_tasks += m
+            opname = ("", "TRSM", "SYRK", "GEMM")[code]
+            self._perf(opname, time.perf_counter() - t0, (1.0, 1.0, 1.0, 2.0)[code] * m * B * B * B)
+            for q, (idx, h, _) in enumerate(items):
+                if rc != 0:
+                    out[idx] = ProcessStatus(f"Exception: [Worker][{opname}] d{opname.lower()} info={rc}")
+                    continue
+                try:
+                    h.send_result(h.getExpectedResults()[0], DeviceBlob(res[q * B * B:(q + 1) * B * B])).get()
+                    out[idx] = ProcessStatus.Ok
+                except Exception as e:
+                    out[idx] = ProcessStatus("send_result failed: " + str(e))
+        return out
 
 
 def main() -> int:

@@ -94,6 +94,12 @@ int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, i
                      int ln, int i, int j, int m, int n, int p, int q);
 int chol_desc_destroy(chol_desc_t **desc);
 
+/* Names the CONTENT behind a 1-tile descriptor's device buffer (the worker: a hash of the write-once result id
+ * its blob belongs to; 0 = unnamed).  chol_potrf_tile on a tagged in-place device tile keeps the tile's block
+ * inverses; chol_trsm_tile with an L of the same buffer AND tag reuses them instead of re-inverting L(k,k) for
+ * every TRSM task of the wave (W2:323 is called once per panel tile with the same L). */
+int chol_desc_set_version(chol_desc_t *desc, unsigned long long version);
+
 /* CHAMELEON_dpotrf_Tile(uplo, A) W2:238, V6:56 (spotrf by descriptor dtype).
  * Works on a 1-tile descriptor (worker path), on a whole tiled matrix (driver path: the full wave
  * DAG of C2:506-565 runs on the device) and on a p x q block-cyclic descriptor (one process per GPU,
@@ -120,6 +126,22 @@ int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double bet
  * Supported: (NoTrans, Trans), any alpha/beta. 1-tile descriptors. */
 int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
                    double beta, chol_desc_t *C);
+
+/* The tasks of ONE op class of a wave in one grouped launch ("submit a whole wave, one wait per
+ * wave"; W2:323 / 416 / 511 executed for n tasks at once), on HBM-resident mb x mb tiles (mb a multiple of 128):
+ *   CHOL_BATCH_TRSM  c_out[t] = c_in[t] * a[t]^{-T}           (Right, Lower, Trans, NonUnit; a[t] = L(k,k))
+ *   CHOL_BATCH_SYRK  c_out[t] = c_in[t] - a[t] a[t]^T, lower triangle (the strict upper triangle is copied)
+ *   CHOL_BATCH_GEMM  c_out[t] = c_in[t] - a[t] b[t]^T
+ * c_in / a / b / c_out: HOST arrays of n device pointers (b ignored unless GEMM).  Every task first takes its
+ * private copy c_out[t] <- c_in[t] (W2:212-213), then the same kernels as the one-tile calls update it: results
+ * are bit-identical to n calls of chol_trsm_tile / chol_syrk_tile / chol_gemm_tile on device buffers.
+ * flags: CHOL_BATCH_ASYNC -- return once the work is enqueued on the library's stream (later library calls are
+ * ordered behind it; chol_sync() waits for it). */
+enum { CHOL_BATCH_TRSM = 1, CHOL_BATCH_SYRK = 2, CHOL_BATCH_GEMM = 3 };
+enum { CHOL_BATCH_ASYNC = 1 };
+int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
+                    const void *const *b, void *const *c_out, int flags);
+int chol_sync(void);
 
 /* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: Chameleon's generator (published
  * core_dplgsy: 64-bit LCG with jump-ahead, entry (i,j), i >= j, = 0.5 - ran_{i + j*m} / 2^64,
@@ -260,6 +282,11 @@ int chol_dist_last_stats(double *issue_us_per_wave, long long *sends, long long 
 int chol_dist_gather_lower(chol_desc_t *src, chol_desc_t *dst, int root);
 
 /* ---- test hooks of the distributed path (never used by chol_potrf_tile) --- */
+/* A transport that moves nothing: sends vanish, receives deliver zeros (stream-ordered).  Lets one process play
+ * any single rank of a p x q grid on a one-GPU box and time that rank's schedule with communication taken as
+ * free; the numerical result is meaningless. */
+int chol_set_transport_null(void);
+
 /* One message of `bytes` bytes (a positive multiple of 8) from this rank to itself on EACH channel of the
  * installed transport, both groups in flight together on the walker's two communication streams,
  * byte-compared.  On a one-rank RCCL communicator: ncclSend / ncclRecv to self inside one group. */

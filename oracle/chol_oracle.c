@@ -213,8 +213,14 @@ ORC_API void orc_plgsy_tiles(double *T, int Nb, int B, double bump, uint64_t see
 
 /* The tiles on or below the diagonal only (what the factorisation reads), one jump per tile column and
  * the LCG running down it -- the same values as orc_plgsy_tiles, ~30x faster: the CPU baseline's input. */
+ORC_API void orc_plgsy_tiles_lower_of(double *T, int Nb, int B, double bump, uint64_t seed, int64_t order);
 ORC_API void orc_plgsy_tiles_lower(double *T, int Nb, int B, double bump, uint64_t seed) {
-  const uint64_t N = (uint64_t)Nb * (uint64_t)B;
+  orc_plgsy_tiles_lower_of(T, Nb, B, bump, seed, (int64_t)Nb * B);
+}
+/* ... the leading Nb x Nb tiles of the matrix of order `order` >= Nb*B (entry (i,j) depends on the order through
+ * the LCG position i + j*order): the leading block of a large factor is the factor of this leading block. */
+ORC_API void orc_plgsy_tiles_lower_of(double *T, int Nb, int B, double bump, uint64_t seed, int64_t order) {
+  const uint64_t N = (uint64_t)order;
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int J = 0; J < Nb; ++J)
     for (int I = 0; I < Nb; ++I) {

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         L.orc_plgsy_matrix.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_plgsy_tiles.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_plgsy_tiles_lower.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
+        L.orc_plgsy_tiles_lower_of.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int64]
+        L.orc_plgsy_tiles_lower_of.restype = None
         L.orc_dgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                    C.c_double, _dp, C.c_int]
         L.orc_dsyrk_ln.argtypes = [C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_double, _dp, C.c_int]
@@ -134,11 +136,12 @@ def plgsy_tiles(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- tile ops
-def plgsy_tiles_lower(Nb: int, B: int, bump: float, seed: int) -> np.ndarray:
+def plgsy_tiles_lower(Nb: int, B: int, bump: float, seed: int, order: int | None = None) -> np.ndarray:
     """Tile layout with only the tiles on or below the diagonal filled (the others are zero): the
-    factorisation's input, generated one tile column at a time (fast)."""
+    factorisation's input, generated one tile column at a time (fast).  order > Nb*B: the leading Nb x Nb
+    tiles of the larger matrix of that order."""
     T = np.zeros(Nb * Nb * B * B, dtype=np.float64)
-    lib().orc_plgsy_tiles_lower(T, Nb, B, float(bump), int(seed))
+    lib().orc_plgsy_tiles_lower_of(T, Nb, B, float(bump), int(seed), int(order if order else Nb * B))
     return T
 
 

@@ -155,11 +155,17 @@ def _run(world, N, B, mode=1, bad=None, grid=None):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, mode, bad, q, grid)) for r in range(world)]
     for p in procs:
+        p.daemon = True  # a rank that hangs must not keep the test runner from exiting
         p.start()
-    got = [q.get(timeout=240) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        got = [q.get(timeout=240) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     return got
 
 

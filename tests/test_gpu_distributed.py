@@ -51,6 +51,23 @@ def test_pxq_rehearsal_on_one_gpu(P, Q, N, B, dtype, cham, orc):
     ch.CHAMELEON_Desc_Destroy(full)
 
 
+@pytest.mark.parametrize("P,Q,N,B", [(2, 2, 2000, 256), (2, 3, 1500, 192)])
+def test_pxq_rehearsal_ragged_order_and_odd_tiles(P, Q, N, B, cham, orc):
+    """N not a multiple of the tile, tile not a multiple of 128, on a p x q grid: every rank keeps its padded image."""
+    from dense_linear_app_amd import distributed as dd
+
+    ch = cham
+    info, full, _ = dd.rehearse(N, B, P, Q)
+    assert info == 0
+    A = orc.plgsy_matrix(N, float(N), 42)
+    Lref, iref = orc.cholesky_lower_any(A, B)
+    assert iref == 0
+    L = np.tril(full.to_lapack())
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() <= 1e-12
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-13
+    ch.CHAMELEON_Desc_Destroy(full)
+
+
 def test_one_by_one_through_the_rehearsal_is_the_walker(cham):
     """p = q = 1 is the same code path as chol_potrf_tile on an ordinary descriptor: bit-identical factors."""
     from dense_linear_app_amd import distributed as dd
@@ -129,11 +146,17 @@ def test_potrf_tile_on_a_pxq_descriptor(world, bad, grid, dtype, orc):
     port = _free_port()
     procs = [ctx.Process(target=_worker_cabi, args=(r, world, port, N, B, q, bad, grid, dtype)) for r in range(world)]
     for p in procs:
+        p.daemon = True  # a rank that hangs must not keep the test runner from exiting
         p.start()
-    got = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     if bad is not None:
         assert [info for _, info, _, _ in got] == [bad + 1] * world
         return

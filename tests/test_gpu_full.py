@@ -140,6 +140,61 @@ def test_full_potrf_large_properties(cham, N, B):
         assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
 
 
+def _compare_leading_tiles(ch, orc, d, N, B, Nb_lead, tol):
+    """The leading Nb_lead x Nb_lead tiles of the factor in `d` against the oracle's factorisation of the leading
+    block of the same matrix (the leading block of a Cholesky factor is the factor of the leading block), tile by tile."""
+    T = orc.plgsy_tiles_lower(Nb_lead, B, float(N), 42, order=N)
+    assert orc.tiled_potrf(T, Nb_lead, B) == 0
+    T = T.reshape(Nb_lead * Nb_lead, B, B)
+    scale = max(np.abs(T[I + J * Nb_lead]).max() for J in range(Nb_lead) for I in range(J, Nb_lead))
+    worst = 0.0
+    for J in range(Nb_lead):
+        for I in range(J, Nb_lead):
+            ref = T[I + J * Nb_lead].T  # (tile stored column-major: element (ii, jj) at ii + jj*B)
+            got = d.download_tile(I, J)
+            diff = np.tril(got) - np.tril(ref) if I == J else got - ref
+            worst = max(worst, np.abs(diff).max() / scale)
+    assert worst <= tol, worst
+
+
+@pytest.mark.parametrize("N,B", [(16384, 512), (16384, 1024)])
+def test_config2_matches_the_oracle_entry_by_entry(cham, orc, N, B):
+    """BASELINE config 2 (N=16384, tile=512; and tile=1024) against the CPU oracle's wave DAG on the same input,
+    every entry of the factor: max|dL| / max|L| <= 1e-12 (v6_test.c:56 on the same matrix)."""
+    ch = cham
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    _compare_leading_tiles(ch, orc, d, N, B, N // B, 1e-12)
+    ch.CHAMELEON_Desc_Destroy(d)
+
+
+@pytest.mark.parametrize("N,B,dtype,lead,tol", [(32768, 512, "f64", 8192, 1e-12), (65536, 1024, "f64", 8192, 1e-12),
+                                                (131072, 1024, "f32", 4096, 1e-4)])
+def test_configs_3_to_5_leading_block_matches_the_oracle(cham, orc, N, B, dtype, lead, tol):
+    """BASELINE configs 3-5 at full size: the leading `lead` x `lead` block of the factor, entry by entry, against
+    the oracle's factorisation of the leading block of the same (order-N) matrix; the rest is covered by the residual."""
+    ch = cham
+    dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
+    d = full_desc(ch, N, B, dt)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    if dtype == "f32":
+        T = orc.plgsy_tiles_lower(lead // B, B, float(N), 42, order=N).astype(np.float32)
+        assert orc.tiled_potrf(T, lead // B, B) == 0
+        T = T.reshape((lead // B) ** 2, B, B).astype(np.float64)
+        nb = lead // B
+        scale = max(np.abs(T[I + J * nb]).max() for J in range(nb) for I in range(J, nb))
+        for J in range(nb):
+            for I in range(J, nb):
+                ref, got = T[I + J * nb].T, d.download_tile(I, J).astype(np.float64)
+                diff = np.tril(got) - np.tril(ref) if I == J else got - ref
+                assert np.abs(diff).max() / scale <= tol, (I, J)
+    else:
+        _compare_leading_tiles(ch, orc, d, N, B, lead // B, tol)
+    ch.CHAMELEON_Desc_Destroy(d)
+
+
 @pytest.mark.parametrize("N,B,dtype,tol", [(65536, 1024, "f64", 1e-13), (65536, 1024, "f32", 5e-5),
                                            (131072, 1024, "f32", 5e-5)])
 def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
@@ -300,13 +355,22 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
     dB.from_lapack(Bm.astype(npdt))
     assert ch.CHAMELEON_dposv_Tile(ch.ChamLower, dA, dB) == N // 2 + 1
     assert np.array_equal(dB.to_lapack(), Bm.astype(npdt))
-    with pytest.raises(ch.CholmiError):
-        ch.CHAMELEON_dpotrs_Tile(ch.ChamUpper, dA, dB)
+    # ChamUpper: factor and solve with U (A = U^T U) on the same storage; same solution to rounding
+    if N % B == 0:
+        dA.from_lapack(A.astype(npdt))
+        dB.from_lapack(Bm.astype(npdt))
+        assert ch.CHAMELEON_dpotrf_Tile(ch.ChamUpper, dA) == 0
+        assert ch.CHAMELEON_dpotrs_Tile(ch.ChamUpper, dA, dB) == 0
+        gotu = dB.to_lapack().astype(np.float64)
+        assert np.abs(gotu - X).max() / np.abs(X).max() <= tol
+        U = np.triu(dA.to_lapack().astype(np.float64))
+        assert np.linalg.norm(U.T @ U - A) / np.linalg.norm(A) <= (1e-13 if dt == "f64" else 5e-5)
 
 
-@pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_U1_CONCURRENT": "0"},
+@pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"},
                                  {"CHOLMI_PAIR_MAX_MB": "0", "CHOLMI_VARIANT": "0"}, {"CHOLMI_TRSM_FUSED_MIN": "1"},
-                                 {"CHOLMI_CHAIN_INSTREAM": "1", "CHOLMI_PAIR_FACTOR": "0"},
+                                 # pairs entered behind a wave launched as near / far halves (wave 0 stays plain), left at the end
+                                 {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"},
                                  # the chain-bound form (device-side counters): off (events only), from the
                                  # first wave on, and entered late (event-linked waves first, then counters)
                                  {"CHOLMI_DEVICE_FLAGS": "0"}, {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"},

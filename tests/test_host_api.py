@@ -318,5 +318,8 @@ def test_v3_long_option_front_end_argument_checks():
     assert run(bsiz=100)[1] == "Error: --bsiz < mb*nb (bsiz=100 mb=256 nb=256).\n"
     assert run(i=4096)[1] == "Error: invalid offsets i=4096 j=0 (lm=2048 ln=2048).\n"
     assert "outside lm=2048" in run(i=512)[1]
+    # --mat user: the buffer is whole tiles (v3:205-212); a ragged order is an error line, not a traceback
+    rc, err = run(mat="user", lm=2000, ln=2000, m=2000, n=2000, N=2000)
+    assert rc == 1 and err.startswith("Error: --mat user needs lm, ln multiples of mb, nb")
     assert driver.v3_test(["--help"], out=io.StringIO(), err=io.StringIO()) == 0
     assert driver.v3_test(["--bogus", "1"], out=io.StringIO(), err=io.StringIO()) == 1
