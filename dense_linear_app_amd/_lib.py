@@ -79,8 +79,10 @@ def lib() -> C.CDLL:
         "chol_set_transport_null": ([], i),
         "chol_dist_rehearse": ([i, i, i, i, i, d, u64, vp, C.POINTER(d)], i),
         "chol_desc_set_version": ([vp, u64], i),
-        "chol_tile_batch": ([i, i, i, i, vp, vp, vp, vp, i], i),
+        "chol_tile_batch": ([i, i, i, i, vp, vp, vp, vp, vp, i], i),
         "chol_sync": ([], i),
+        "chol_potrf_batch": ([i, i, i, vp, vp, vp, C.POINTER(i), i], i),
+        "chol_batch_info": ([i, C.POINTER(i)], i),
         "chol_debug_calibration": ([C.POINTER(d)], i),
         "chol_debug_update_kernel": ([i, C.c_char_p, i], i),
         "chol_dist_last_stats": ([C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i),

@@ -29,9 +29,20 @@ polling agent drives one Execute at a time, W2:593).
 """
 from __future__ import annotations
 
+import itertools
 import uuid
 from dataclasses import dataclass, field
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+
+_ID_PREFIX = uuid.uuid4().hex[:12]
+_ID_COUNTER = itertools.count(1)
+
+
+def _new_id() -> str:
+    """An opaque unique id (the ArmoniK server hands out uuids; here: a per-process random prefix and a counter,
+    a tenth of the cost of uuid4 -- it is paid three times per task)."""
+    return f"{_ID_PREFIX}-{next(_ID_COUNTER):08x}"
 
 
 # ------------------------------------------------------------------------------ value types
@@ -90,17 +101,40 @@ class DeviceBlob:
     """A result that lives in HBM: same wire format (raw column-major doubles), different address
     space.  With `ControlPlane(device_results=True)` tiles are uploaded once, every task's inputs
     and output stay on the GPU, and only `download_result_data` copies back -- the MI355X answer
-    to the reference's per-task download/upload of every tile through the object store."""
+    to the reference's per-task download/upload of every tile through the object store.
 
-    def __init__(self, tensor):
-        self.tensor = tensor  # 1-D torch tensor on the GPU (owns the memory)
+    A blob is either a tensor of its own or `count` bytes at `offset` of a parent tensor (the one output
+    allocation of a grouped launch, worker.ExecuteBatch).  Blobs written by an ASYNCHRONOUS grouped launch
+    carry the epoch of that launch: whoever reads them outside the library's stream calls wait() first."""
+
+    pending_epoch = 0  # grouped launches issued on the library's stream so far
+    synced_epoch = 0   # ... and how many of them a chol_sync() has since waited for
+
+    def __init__(self, tensor, offset: int = 0, count: Optional[int] = None, epoch: int = 0):
+        self._parent = tensor  # 1-D torch tensor on the GPU (owns the memory)
+        self._offset = offset  # in bytes
+        self.nbytes = tensor.numel() * tensor.element_size() if count is None else count
+        self.ptr = tensor.data_ptr() + offset
+        self.epoch = epoch
+        self._view = tensor if (offset == 0 and count is None) else None
 
     @property
-    def nbytes(self) -> int:
-        return self.tensor.numel() * self.tensor.element_size()
+    def tensor(self):
+        if self._view is None:
+            es = self._parent.element_size()
+            self._view = self._parent[self._offset // es:(self._offset + self.nbytes) // es]
+        return self._view
 
     def __len__(self) -> int:
         return self.nbytes
+
+    def wait(self) -> None:
+        """Make the content visible to other streams / the host."""
+        if self.epoch > DeviceBlob.synced_epoch:
+            from ._lib import lib
+
+            lib().chol_sync()
+            DeviceBlob.synced_epoch = DeviceBlob.pending_epoch
 
     @classmethod
     def from_bytes(cls, data) -> "DeviceBlob":
@@ -111,11 +145,7 @@ class DeviceBlob:
         return cls(torch.from_numpy(a.copy()).cuda())
 
     def to_bytes(self) -> bytes:
-        # the tile may still be in flight on the library's own stream (worker.ExecuteBatch issues whole op classes
-        # asynchronously): wait for that stream before torch copies on its own
-        from ._lib import lib
-
-        lib().chol_sync()
+        self.wait()
         return self.tensor.cpu().numpy().tobytes()
 
 
@@ -295,6 +325,31 @@ class ControlPlane:
             if self.on_task_done:
                 self.on_task_done(t)
 
+    def flush(self) -> None:
+        """Wave-level execution may report a task before its kernels have run (worker.async_potrf).  Wait for the
+        workers and apply what they found out since: the task that failed gets its real status, its result and
+        everything computed from it is aborted -- what the one-task path would have reported at once."""
+        failed = {}
+        for w in self._workers.values():
+            if hasattr(w, "flush"):
+                failed.update(dict(w.flush()))
+        if not failed:
+            return
+        aborted = set()
+        for tid in self.executed:
+            t = self._tasks[tid]
+            mine = [k for k in t.expected_output_keys if k in failed]
+            if mine:
+                t.status, t.output = "error", ProcessStatus(failed[mine[0]])
+            elif any(d in aborted for d in [t.payload_id] + t.data_dependencies):
+                t.status, t.output = "error", ProcessStatus("a data dependency was aborted")
+            else:
+                continue
+            for k in t.expected_output_keys:
+                self._results[k].status = "aborted"
+                self._results[k].data = None
+                aborted.add(k)
+
     def _pump(self) -> None:
         progressed = True
         while progressed:
@@ -305,7 +360,7 @@ class ControlPlane:
                 for t in ready:
                     by_part.setdefault(t.options.partition_id, []).append(t)
                 for part, ts in by_part.items():
-                    if len(ts) > 1 and hasattr(self._workers.get(part), "ExecuteBatch"):
+                    if ts and hasattr(self._workers.get(part), "ExecuteBatch"):
                         for t in ts:
                             self._pending.remove(t.task_id)
                         self._run_batch(ts)
@@ -331,7 +386,7 @@ class SessionsClient:
         self._plane = plane
 
     def create_session(self, default_task_option: TaskOptions, partitions: Sequence[str] = ()) -> str:
-        sid = str(uuid.uuid4())
+        sid = _new_id()
         self._plane._sessions[sid] = default_task_option.copy()
         return sid
 
@@ -346,7 +401,7 @@ class ResultsClient:
             raise KeyError(f"unknown session {session_id}")
         out = {}
         for n in names:
-            rid = str(uuid.uuid4())
+            rid = _new_id()
             self._plane._results[rid] = _Result(rid, n, session_id)
             out[n] = rid
         return out
@@ -355,7 +410,7 @@ class ResultsClient:
         if isinstance(data, str):
             data = data.encode("utf-8")
         name = self._plane._results[result_id].name if result_id in self._plane._results else ""
-        if self._plane.device_results and name != "payload" and not isinstance(data, DeviceBlob):
+        if self._plane.device_results and not name.startswith("payload") and not isinstance(data, DeviceBlob):
             data = DeviceBlob.from_bytes(data)  # tiles go to HBM once; payloads stay on the host
         self._plane._complete_result(result_id, data)
         self._plane._pump()
@@ -374,14 +429,15 @@ class TasksClient:
     def submit_tasks(self, session_id: str, task_creations: Sequence[TaskCreation],
                      task_options: Optional[TaskOptions] = None) -> List[str]:
         opts = task_options or self._plane._sessions[session_id]
+        shared = opts.copy()  # (one private copy per submission: the tasks of a call share their options)
         ids = []
         for tc in task_creations:
             for rid in [tc.payload_id, *tc.expected_output_keys, *tc.data_dependencies]:
                 if rid not in self._plane._results:
                     raise KeyError(f"submit_tasks: unknown result id {rid}")
-            tid = str(uuid.uuid4())
+            tid = _new_id()
             self._plane._tasks[tid] = _Task(tid, session_id, tc.payload_id, list(tc.expected_output_keys),
-                                            list(tc.data_dependencies), opts.copy())
+                                            list(tc.data_dependencies), shared)
             self._plane._pending.append(tid)
             ids.append(tid)
         self._plane._pump()

@@ -217,6 +217,8 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
         from .worker import DagCholeskyWorker
 
         worker = DagCholeskyWorker(verbose=verbose, log=log)
+    if batched and device_results and hasattr(worker, "async_potrf"):
+        worker.async_potrf = True  # every class of a wave enqueued; failures surface at plane.flush() below
     plane.register_worker(PARTITION, worker)
     taskOptions = default_task_options()
     tasksClient, resultsClient = ak.TasksClient(plane), ak.ResultsClient(plane)
@@ -299,10 +301,12 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
                     keys.append(block_id_from_ij(i, j))
             for key, o in zip(keys, submit_batch(items)):
                 latest[key] = o
-        if device_results:  # grouped launches are asynchronous on the library's stream: the run ends when they have
-            from ._lib import lib
-
-            lib().chol_sync()
+        if device_results:
+            # grouped launches are asynchronous on the library's stream: the run ends when they have; a tile that
+            # turned out not to be positive definite fails its POTRF task now, and the wait below raises as the
+            # blocking client's wait on that task's output does (C2:499)
+            plane.flush()
+            eventsClient.wait_for_result_availability(session_id, list(latest.values()))
         return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane)
     for k in range(Nb):  # C2:506
         if verbose:

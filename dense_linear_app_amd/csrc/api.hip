@@ -27,6 +27,8 @@ extern "C" int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtyp
 
 namespace {
 
+constexpr int BINFO_SLOTS = 4096;
+
 struct Ctx {
   bool inited = false;
   int rank = 0, nranks = 1;
@@ -43,6 +45,8 @@ struct Ctx {
   unsigned long long wc_version = 0;
   int wc_mb = 0, wc_dtype = 0;
   void *wc_winv = nullptr;
+  int *d_binfo = nullptr;  // device info words of asynchronously factored tiles (chol_potrf_batch), a ring
+  unsigned binfo_next = 0;
   std::string last_error;
 };
 Ctx g;
@@ -671,6 +675,8 @@ int chol_finalize(void) {
   g.work_bytes = 0;
   if (g.wc_winv) (void)hipFree(g.wc_winv);
   g.wc_winv = nullptr;
+  if (g.d_binfo) (void)hipFree(g.d_binfo);
+  g.d_binfo = nullptr;
   g.wc_ptr = nullptr;
   g.wc_version = 0;
   (void)hipFree(g.d_acc);
@@ -833,8 +839,8 @@ int chol_sync(void) {
 
 // ---------------------------------------------------------------- the tasks of one op class in one grouped launch
 template <typename T>
-static int tile_batch_impl(int op, int mb, int n, const void *const *c_in, const void *const *a, const void *const *b,
-                           void *const *c_out) {
+static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a, const void *const *b,
+                           void *const *c_out, const unsigned long long *a_versions) {
   hipStream_t s = g.r.st[ST_MAIN];
   const size_t tb = (size_t)mb * mb * sizeof(T);
   // device copies of the four pointer lists (stream-ordered behind the kernels still reading the last batch's)
@@ -863,8 +869,15 @@ static int tile_batch_impl(int op, int mb, int n, const void *const *c_in, const
       // (at most g_trsm_small_max / nbm tiles per launch: the small-block kernels of the one-tile call, same bits)
       const int per = std::max(1, cholmi::g_trsm_small_max / (mb / MACRO));
       const T *L = reinterpret_cast<const T *>(a[t0]);
-      T *w = reinterpret_cast<T *>(g.r.winv);
-      launch_invert_diag<T>(s, L, mb, w);
+      // the block inverses the POTRF task of this L left behind (same bits as the one-tile call finds), else recomputed
+      const T *w = reinterpret_cast<const T *>(cached_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype));
+      if (!w) {
+        T *wn = reinterpret_cast<T *>(g.r.winv);
+        launch_invert_diag<T>(s, L, mb, wn);
+        rc = remember_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype, (size_t)(mb / MACRO) * MACRO * MACRO * sizeof(T));
+        if (rc) return rc;
+        w = wn;
+      }
       for (int q = t0; q < t1; q += per)
         launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[q]), (long)mb * mb, std::min(per, t1 - q), L, w, mb, T(1));
       t0 = t1;
@@ -874,10 +887,57 @@ static int tile_batch_impl(int op, int mb, int n, const void *const *c_in, const
   return 0;
 }
 
+// POTRF of n HBM-resident tiles, each on its private copy, info per tile in a device slot (read after chol_sync)
+template <typename T>
+static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
+                            const unsigned long long *versions, int *slots) {
+  hipStream_t s = g.r.st[ST_MAIN];
+  const size_t tb = (size_t)mb * mb * sizeof(T);
+  if (!g.d_binfo) HIPCHECK(hipMalloc(&g.d_binfo, BINFO_SLOTS * sizeof(int)));
+  for (int t = 0; t < n; ++t) {
+    const int slot = (int)(g.binfo_next++ % BINFO_SLOTS);
+    slots[t] = slot;
+    HIPCHECK(hipMemsetAsync(g.d_binfo + slot, 0, sizeof(int), s));
+    HIPCHECK(hipMemcpyAsync(a_out[t], a_in[t], tb, hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
+    launch_potrf_tile<T>(s, reinterpret_cast<T *>(a_out[t]), mb, reinterpret_cast<T *>(g.r.winv), g.d_binfo + slot, 0,
+                         tile_sems());
+    int rc = remember_winv(a_out[t], versions ? versions[t] : 0, mb, dtype, (size_t)(mb / MACRO) * MACRO * MACRO * sizeof(T));
+    if (rc) return rc;
+    if (!versions || !versions[t]) forget_winv(a_out[t]);
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
+int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
+                     const unsigned long long *versions, int *slots, int flags) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_batch before chol_init");
+  if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-1, "potrf_batch: dtype");
+  if (mb <= 0 || mb % MACRO || mb > 4096) return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_batch: tile edge must be a multiple of 128, at most 4096");
+  if (n < 0 || n > BINFO_SLOTS / 2) return fail(-3, "potrf_batch: n");
+  if (n == 0) return 0;
+  if (!a_in || !a_out || !slots) return fail(-4, "potrf_batch: NULL pointer list");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int rc = dtype == CHOL_REAL_DOUBLE ? potrf_batch_impl<double>(dtype, mb, n, a_in, a_out, versions, slots)
+                                           : potrf_batch_impl<float>(dtype, mb, n, a_in, a_out, versions, slots);
+  if (rc) return rc;
+  if (!(flags & CHOL_BATCH_ASYNC)) HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  return 0;
+}
+
+int chol_batch_info(int slot, int *info) {
+  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "batch_info before chol_init");
+  if (!info || slot < 0 || slot >= BINFO_SLOTS || !g.d_binfo) return fail(-1, "batch_info: slot");
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  HIPCHECK(hipMemcpy(info, g.d_binfo + slot, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
-                    const void *const *b, void *const *c_out, int flags) {
+                    const void *const *b, void *const *c_out, const unsigned long long *a_versions, int flags) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "tile_batch before chol_init");
   if (op != CHOL_BATCH_TRSM && op != CHOL_BATCH_SYRK && op != CHOL_BATCH_GEMM) return fail(-1, "tile_batch: op");
   if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-2, "tile_batch: dtype");
@@ -886,8 +946,8 @@ int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, c
   if (n == 0) return 0;
   if (!c_in || !a || !c_out || (op == CHOL_BATCH_GEMM && !b)) return fail(-5, "tile_batch: NULL pointer list");
   std::lock_guard<std::mutex> lk(g_mu);
-  const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, mb, n, c_in, a, b, c_out)
-                                           : tile_batch_impl<float>(op, mb, n, c_in, a, b, c_out);
+  const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, dtype, mb, n, c_in, a, b, c_out, a_versions)
+                                           : tile_batch_impl<float>(op, dtype, mb, n, c_in, a, b, c_out, a_versions);
   if (rc) return rc;
   if (!(flags & CHOL_BATCH_ASYNC)) HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;

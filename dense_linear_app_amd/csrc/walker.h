@@ -286,11 +286,14 @@ struct Walker {
         WRC(before());
         for (int c2 = 0; c2 < g.Q; ++c2)  // along the process row: the whole part
           if (c2 != dc) WRC(cm->send(1, src, (size_t)cnt * g.tile_bytes, g.rank_of(p2, c2), st));
-        for (int r2 = 0; r2 < g.P; ++r2) {  // to the other process rows: tile j to process column j mod q
+        for (int r2 = 0; r2 < g.P; ++r2) {  // to the other process rows: tile j to process column j mod q ...
           if (r2 == p2) continue;
-          for (int t = 0; t < cnt; ++t) {
-            const int j = (il0 + t) * g.P + p2;
-            WRC(cm->send(1, src + (size_t)t * g.tile_bytes, g.tile_bytes, g.rank_of(r2, j % g.Q), st));
+          for (int t = 0; t < cnt;) {  // ... runs of consecutive tiles for the same rank as one message
+            const int c = ((il0 + t) * g.P + p2) % g.Q;
+            int t1 = t + 1;
+            while (t1 < cnt && ((il0 + t1) * g.P + p2) % g.Q == c) ++t1;
+            WRC(cm->send(1, src + (size_t)t * g.tile_bytes, (size_t)(t1 - t) * g.tile_bytes, g.rank_of(r2, c), st));
+            t = t1;
           }
         }
       } else {
@@ -301,11 +304,16 @@ struct Walker {
           WRC(before());
           WRC(cm->recv(1, buf, (size_t)cnt * g.tile_bytes, g.rank_of(p2, dc), st));
         } else {
-          for (int t = 0; t < cnt; ++t) {
-            const int j = (il0 + t) * g.P + p2;
-            if (j % g.Q != g.pc) continue;
+          for (int t = 0; t < cnt;) {  // the sender's runs: consecutive tiles of my process column
+            if (((il0 + t) * g.P + p2) % g.Q != g.pc) {
+              ++t;
+              continue;
+            }
+            int t1 = t + 1;
+            while (t1 < cnt && ((il0 + t1) * g.P + p2) % g.Q == g.pc) ++t1;
             WRC(before());
-            WRC(cm->recv(1, buf + (size_t)t * g.tile_bytes, g.tile_bytes, g.rank_of(p2, dc), st));
+            WRC(cm->recv(1, buf + (size_t)t * g.tile_bytes, (size_t)(t1 - t) * g.tile_bytes, g.rank_of(p2, dc), st));
+            t = t1;
           }
         }
       }

@@ -25,11 +25,24 @@ import numpy as np
 
 
 def grid_for(nranks: int) -> Tuple[int, int]:
-    """1x1, 1x2, 2x2, 2x4 for 1/2/4/8 GPUs; P <= Q in general."""
-    p = int(math.isqrt(nranks))
-    while nranks % p:
-        p -= 1
-    return p, nranks // p
+    """The process grid for `nranks` GPUs: as square as possible, P >= Q -- 1x1, 2x1, 2x2, 4x2 for 1/2/4/8.
+    Tall rather than wide (SURVEY 8e suggests 2x4): what bounds a wave once the update is short is the panel cycle
+    TRSM -> exchange -> update of column k+1, whose critical transfer is the part of the panel one process row holds
+    (nt/P tiles) over ONE xGMI link to the next process column; a tall grid halves that part and the local TRSM, and
+    the fully connected links carry the extra column-operand messages side by side (scripts/grid_model.py:
+    2x4 5.7x, 4x2 6.8x of the measured 1-GPU time at N=65536, tile 1024).  CHOLMI_GRID=PxQ overrides."""
+    import os
+
+    env = os.environ.get("CHOLMI_GRID")
+    if env:
+        p, q = (int(x) for x in env.lower().split("x"))
+        if p * q != nranks:
+            raise ValueError(f"CHOLMI_GRID={env} does not match {nranks} ranks")
+        return p, q
+    q = int(math.isqrt(nranks))
+    while nranks % q:
+        q -= 1
+    return nranks // q, q
 
 
 def owner_of(I: int, J: int, P: int, Q: int) -> int:

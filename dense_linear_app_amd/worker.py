@@ -139,6 +139,7 @@ class _DevTile:
         import torch
 
         n = blob.nbytes // 8
+        blob.wait()  # (the blob may still be in flight on the library's stream: a grouped launch of ExecuteBatch)
         self.t = blob.tensor.view(torch.uint8)[:n * 8].clone()
         torch.cuda.current_stream().synchronize()  # libcholmi runs on its own (non-blocking) stream
         self.size = n
@@ -158,14 +159,14 @@ class _DevView:
     never writes its A / L operands)."""
 
     def __init__(self, blob: DeviceBlob):
-        self.t = blob.tensor
+        self.blob = blob
         self.size = blob.nbytes // 8
 
     def data_ptr(self) -> int:
-        return self.t.data_ptr()
+        return self.blob.ptr
 
     def host(self) -> np.ndarray:
-        return np.frombuffer(self.t.cpu().numpy().tobytes(), dtype=np.float64)
+        return np.frombuffer(self.blob.to_bytes(), dtype=np.float64)
 
 
 def _to_doubles(blob, readonly: bool = False):
@@ -188,6 +189,11 @@ class DagCholeskyWorker(ArmoniKWorker):
         self._tags = isinstance(self.backend, HipTileBackend)
         self.batches = 0        # grouped launches issued by ExecuteBatch
         self.batched_tasks = 0  # tasks they covered
+        # POTRF tasks inside ExecuteBatch: False -- one synchronous call each, info known before the task reports;
+        # True -- enqueued like the other classes (chol_potrf_batch), the task reports Ok at once and a failing
+        # factorisation is discovered by flush() (the client of the wave-level mode calls it once, at the end)
+        self.async_potrf = False
+        self._deferred: list = []  # (output result id, device info slot, B) of asynchronously factored tiles
 
     # -- diagnostics of W2:120-148 (opt-in)
     def _diag(self, tag: str, **arrays):
@@ -348,52 +354,104 @@ class DagCholeskyWorker(ArmoniKWorker):
             try:
                 p = handle_json(h.getPayload())
                 code = self._BATCH_OP.get(p.op)
+                if code is None and p.op == "POTRF" and self.async_potrf:
+                    code = 4
                 if code is None or p.B <= 0 or p.B % 128:
                     out[idx] = self.Execute(h)
                     continue
-                names = (p.inA, p.inL) if code == 1 else (p.inC, p.inA) if code == 2 else (p.inC, p.inAi, p.inAj)
+                names = ((p.inA, p.inL) if code == 1 else (p.inC, p.inA) if code == 2 else (p.inC, p.inAi, p.inAj) if code == 3
+                         else (p.in_,))
                 deps = h.getDataDependencies()
                 blobs = [deps.get(x) for x in names]
                 want = p.B * p.B * 8
                 if any(not isinstance(b, DeviceBlob) or b.nbytes != want for b in blobs):
                     out[idx] = self.Execute(h)  # (missing / short / host blobs: the per-task path reports them)
                     continue
-                groups.setdefault((code, p.B), []).append((idx, h, blobs))
+                groups.setdefault((code, p.B), []).append((idx, h, blobs, _tag_of(p.inL) if code == 1 else 0))
             except Exception as e:  # W2:558-560
                 out[idx] = ProcessStatus("Exception: " + str(e))
         if groups:
             torch.cuda.current_stream().synchronize()  # uploads made through torch are visible to the library's stream
         for (code, B), items in groups.items():
             m = len(items)
-            res = torch.empty(m * B * B, dtype=torch.float64, device=items[0][2][0].tensor.device)
+            res = torch.empty(m * B * B, dtype=torch.float64, device="cuda")
             base, tb = res.data_ptr(), B * B * 8
-            ptr = np.empty((4, m), dtype=np.uint64)
-            for q, (_, _, blobs) in enumerate(items):
-                ptr[0, q] = blobs[0].tensor.data_ptr()
-                ptr[1, q] = blobs[1].tensor.data_ptr()
-                ptr[2, q] = blobs[2].tensor.data_ptr() if code == 3 else 0
+            ptr = np.empty((5, m), dtype=np.uint64)
+            for q, (_, _, blobs, tag) in enumerate(items):
+                ptr[0, q] = blobs[0].ptr
+                ptr[1, q] = blobs[1].ptr if code != 4 else 0
+                ptr[2, q] = blobs[2].ptr if code == 3 else 0
+                ptr[4, q] = tag
             ptr[3, :] = base + tb * np.arange(m, dtype=np.uint64)
+            if code == 4:  # POTRF: enqueued, the output tagged with its result id, info left in a device slot
+                outs = [h.getExpectedResults()[0] for _, h, _, _ in items]
+                ptr[4] = [_tag_of(o) for o in outs]
+                slots = (C.c_int * m)()
+                t0 = time.perf_counter()
+                rc = lib().chol_potrf_batch(ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[3].ctypes.data,
+                                            ptr[4].ctypes.data, slots, 1)
+                self.batches += 1
+                self.batched_tasks += m
+                DeviceBlob.pending_epoch += 1
+                epoch = DeviceBlob.pending_epoch
+                self._perf("POTRF", time.perf_counter() - t0, (1.0 / 3.0) * m * B * B * B)
+                for q, (idx, h, _, _) in enumerate(items):
+                    if rc != 0:
+                        out[idx] = ProcessStatus(f"Exception: [Worker][POTF] dpotrf info={rc}")
+                        continue
+                    try:
+                        h.send_result(outs[q], DeviceBlob(res, q * tb, tb, epoch)).get()
+                        self._deferred.append((outs[q], int(slots[q])))
+                        out[idx] = ProcessStatus.Ok
+                    except Exception as e:
+                        out[idx] = ProcessStatus("[Worker][POTF] send_result failed: " + str(e))
+                continue
             if code == 1:  # panels: the tasks that share an L side by side
                 order = np.argsort(ptr[1], kind="stable")
                 ptr[:3] = ptr[:3, order]
+                ptr[4] = ptr[4, order]
                 items = [items[int(o)] for o in order]
             t0 = time.perf_counter()
             rc = lib().chol_tile_batch(code, ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[1].ctypes.data,
-                                       ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data, 1)
+                                       ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data,
+                                       ptr[4].ctypes.data if code == 1 else None, 1)
             self.batches += 1
             self.batched_tasks += m
+            DeviceBlob.pending_epoch += 1
+            epoch = DeviceBlob.pending_epoch
             opname = ("", "TRSM", "SYRK", "GEMM")[code]
             self._perf(opname, time.perf_counter() - t0, (1.0, 1.0, 1.0, 2.0)[code] * m * B * B * B)
-            for q, (idx, h, _) in enumerate(items):
+            for q, (idx, h, _, _) in enumerate(items):
                 if rc != 0:
                     out[idx] = ProcessStatus(f"Exception: [Worker][{opname}] d{opname.lower()} info={rc}")
                     continue
                 try:
-                    h.send_result(h.getExpectedResults()[0], DeviceBlob(res[q * B * B:(q + 1) * B * B])).get()
+                    h.send_result(h.getExpectedResults()[0], DeviceBlob(res, q * tb, tb, epoch)).get()
                     out[idx] = ProcessStatus.Ok
                 except Exception as e:
                     out[idx] = ProcessStatus("send_result failed: " + str(e))
         return out
+
+    def flush(self) -> list:
+        """Wait for everything ExecuteBatch enqueued and collect what it could not know when it reported:
+        -> [(output result id, message)] of the asynchronously factored tiles whose dpotrf info is not 0, with
+        the message the synchronous path gives (W2:243-244)."""
+        import ctypes as C
+
+        from ._lib import lib
+
+        failed = []
+        for out_id, slot in self._deferred:
+            info = C.c_int()
+            if lib().chol_batch_info(slot, C.byref(info)) != 0:
+                failed.append((out_id, "Exception: [Worker][POTF] dpotrf info=?"))
+            elif info.value != 0:
+                failed.append((out_id, "Exception: [Worker][POTF] dpotrf info=" + str(info.value)))
+        self._deferred = []
+        if not failed:
+            lib().chol_sync()
+        DeviceBlob.synced_epoch = DeviceBlob.pending_epoch
+        return failed
 
 
 def main() -> int:

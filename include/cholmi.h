@@ -135,13 +135,23 @@ int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_de
  * c_in / a / b / c_out: HOST arrays of n device pointers (b ignored unless GEMM).  Every task first takes its
  * private copy c_out[t] <- c_in[t] (W2:212-213), then the same kernels as the one-tile calls update it: results
  * are bit-identical to n calls of chol_trsm_tile / chol_syrk_tile / chol_gemm_tile on device buffers.
+ * a_versions (may be NULL): content tags of the a[t] buffers (chol_desc_set_version's meaning) -- TRSM reuses
+ * the block inverses kept for (a[t], tag) by the POTRF task instead of re-inverting L(k,k).
  * flags: CHOL_BATCH_ASYNC -- return once the work is enqueued on the library's stream (later library calls are
  * ordered behind it; chol_sync() waits for it). */
 enum { CHOL_BATCH_TRSM = 1, CHOL_BATCH_SYRK = 2, CHOL_BATCH_GEMM = 3 };
 enum { CHOL_BATCH_ASYNC = 1 };
 int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
-                    const void *const *b, void *const *c_out, int flags);
+                    const void *const *b, void *const *c_out, const unsigned long long *a_versions, int flags);
 int chol_sync(void);
+/* The POTRF tasks of a wave the same way: a_out[t] <- a_in[t] (private copy), factored Lower in place.  versions
+ * (may be NULL) tags a_out[t]'s content, so that its block inverses serve the TRSM batch that follows.  The
+ * LAPACK info of task t lands in a device slot: slots[t] (host array of n ints) receives its index, and
+ * chol_batch_info(slot, &info) reads it (after waiting for the library's stream).  With CHOL_BATCH_ASYNC the call
+ * returns at once: a failing factorisation is discovered when the caller asks. */
+int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
+                     const unsigned long long *versions, int *slots, int flags);
+int chol_batch_info(int slot, int *info);
 
 /* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: Chameleon's generator (published
  * core_dplgsy: 64-bit LCG with jump-ahead, entry (i,j), i >= j, = 0.5 - ran_{i + j*m} / 2^64,

@@ -5,7 +5,7 @@ result is meaningless -- the panels it would have received are missing -- but th
 Reported per rank: the host time of the walker per wave (chol_dist_last_stats), the transport operations it
 posted, and the DEVICE time of the rank's whole schedule (chol_last_potrf_stats): its compute with communication
 taken as free -- the per-rank input of the critical-path projection in DESIGN.md section 5.
-    python scripts/dist_issue_time.py [N tile]      (default 65536 1024, grids 1x1, 1x2, 2x2, 2x4, every rank)"""
+    python scripts/dist_issue_time.py [N tile]      (default 65536 1024; grids 1x1, 2x1, 2x2, 4x2 -- the defaults -- and 2x4, 8x1, every rank)"""
 import ctypes as C
 import os
 import sys
@@ -18,8 +18,8 @@ from dense_linear_app_amd._lib import lib
 N, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (65536, 1024)
 ch.CHAMELEON_Init(1, 1)
 L = lib()
-for world in (1, 2, 4, 8):
-    P, Q = dd.grid_for(world)
+for P, Q in ((1, 1), (2, 1), (2, 2), (4, 2), (2, 4), (8, 1)):
+    world = P * Q
     for rank in range(world):
         ch.set_rank(rank, world)
         d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, P, Q)

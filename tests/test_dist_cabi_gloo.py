@@ -3,8 +3,8 @@ p x q grid) driven on the CPU: the oracle's tile kernels plugged in through the 
 (chol_dist_factorize_with), the tiles moved by a torch.distributed/gloo transport table -- ownership,
 local indexing, matching of the point-to-point sends and receives along process rows and columns,
 receive-buffer reuse, and the schedule's regimes (panels in pairs, near / far halves, plain waves: `mode`)
-are exactly the product's code path; no compute of the product runs here.  World sizes 1, 2 (1x2), 3 (1x3),
-4 (2x2), 6 (2x3), 8 (2x4) and the tall grids 2x1, 3x1; the result must equal the single-process oracle and
+are exactly the product's code path; no compute of the product runs here.  World sizes 1, 2 (2x1), 3, 4 (2x2), 6 (3x2), 8 (4x2) -- the
+default, tall grids -- and 1x2, 1x3, 2x3, 2x4, 4x1, 8x1 explicitly; the result must equal the single-process oracle and
 every rank must report the same info."""
 import ctypes as C
 import os
@@ -171,7 +171,8 @@ def _run(world, N, B, mode=1, bad=None, grid=None):
 
 @pytest.mark.parametrize("world,mode,grid", [(1, 0, None), (1, 1, None), (1, 2, None), (2, 1, None), (2, 0, None), (2, 2, None),
                                              (4, 1, None), (4, 0, None), (4, 2, None), (6, 1, None), (8, 1, None), (8, 2, None),
-                                             (2, 1, (2, 1)), (3, 1, (3, 1)), (3, 2, (1, 3)), (6, 0, (3, 2))])
+                                             (2, 1, (1, 2)), (3, 1, (3, 1)), (3, 2, (1, 3)), (6, 0, (2, 3)), (8, 1, (2, 4)),
+                                             (8, 0, (8, 1)), (4, 1, (4, 1))])
 def test_c_wave_loop_matches_oracle(world, mode, grid):
     from oracle import oracle as orc
 
@@ -198,7 +199,7 @@ def test_c_wave_loop_matches_oracle(world, mode, grid):
         nt, tile = N // B, B * B * 8
         replicated = sum((nt - 1 - k) * tile * (world - 1) for k in range(nt))
         moved = sum(s["bytes_sent"] for *_, s in got)
-        assert moved < 0.75 * replicated
+        assert moved < 0.85 * replicated  # about (1/p + 1/q) of every panel per rank: 0.75 on 4 x 2 and 2 x 4
 
 
 def test_c_wave_loop_info_is_agreed_by_all_ranks():

@@ -34,7 +34,8 @@ def _check_against_oracle(orc, full, N, B, dtype, tol):
 
 @pytest.mark.parametrize("P,Q,N,B,dtype", [(1, 1, 2304, 256, "f64"), (1, 2, 2304, 256, "f64"), (2, 1, 2304, 256, "f64"),
                                            (2, 2, 2304, 256, "f64"), (3, 1, 2304, 256, "f64"), (2, 3, 2304, 256, "f64"),
-                                           (2, 4, 3328, 256, "f64"), (2, 2, 8192, 512, "f64"), (2, 4, 8192, 512, "f64"),
+                                           (2, 4, 3328, 256, "f64"), (4, 2, 3328, 256, "f64"), (4, 1, 2304, 256, "f64"),
+                                           (2, 2, 8192, 512, "f64"), (4, 2, 8192, 512, "f64"), (2, 4, 8192, 512, "f64"),
                                            (2, 2, 4096, 512, "f32"), (1, 3, 2304, 128, "f32")])
 def test_pxq_rehearsal_on_one_gpu(P, Q, N, B, dtype, cham, orc):
     """The p x q walker with its real kernels, streams, events and receive-buffer rotation: the ranks are threads of
@@ -133,7 +134,8 @@ def _worker_cabi(rank, world, port, N, B, q, bad, grid, dtype):
 
 
 @pytest.mark.parametrize("world,bad,grid,dtype", [(2, None, None, "f64"), (4, None, None, "f64"), (4, 1300, None, "f64"),
-                                                  (2, None, (2, 1), "f64"), (3, None, (3, 1), "f64"), (4, None, None, "f32")])
+                                                  (2, None, (1, 2), "f64"), (3, None, (3, 1), "f64"), (4, None, None, "f32"),
+                                                  (4, None, (4, 1), "f64")])
 def test_potrf_tile_on_a_pxq_descriptor(world, bad, grid, dtype, orc):
     """chol_potrf_tile works for a full P x Q descriptor.  The ranks share the one test GPU
     and the transport table is filled with gloo point-to-point calls (RCCL wants one GPU per rank);

@@ -90,7 +90,8 @@ def test_bench_protocol_csv(cham, tmp_path):
 
 def test_worker_path_device_resident_results(cham, orc):
     """ControlPlane(device_results=True): tiles are uploaded once and every version stays in HBM
-    (armonik.DeviceBlob).  Same kernels, same inputs -> bit-identical to the host-blob path."""
+    (armonik.DeviceBlob).  Same kernels, same inputs; the TRSM tasks reuse the block inverses the POTRF task left
+    behind (content tags) where the host-blob path recomputes them from L(k,k): equal to rounding, not to the bit."""
     import time
 
     from dense_linear_app_amd import armonik as ak, client
@@ -105,7 +106,7 @@ def test_worker_path_device_resident_results(cham, orc):
     assert dev.task_counts == host.task_counts
     blob = dev.plane._results[dev.latest["blk/3/1"]].data
     assert isinstance(blob, ak.DeviceBlob) and blob.tensor.is_cuda
-    assert np.array_equal(dev.lower_factor(), host.lower_factor())
+    assert np.abs(dev.lower_factor() - host.lower_factor()).max() <= 1e-13 * np.abs(host.lower_factor()).max()
     A = orc.reference_input(N)
     L = dev.lower_factor()
     assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-13
@@ -130,7 +131,7 @@ def test_wave_level_execution_is_bit_identical_to_the_per_task_path(cham, orc, N
     assert wave.task_counts == per_task.task_counts
     total = sum(wave.task_counts.values())
     assert len(wave.plane.executed) == total == len(per_task.plane.executed)
-    assert w.batches >= 2 * (N // B - 2) and w.batched_tasks >= total - 3 * (N // B)
+    assert w.batches >= 2 * (N // B - 2) and w.batched_tasks == total  # POTRF tasks included (asynchronous)
     assert isinstance(wave.plane._results[wave.latest["blk/2/1"]].data, ak.DeviceBlob)
     assert np.array_equal(wave.lower_factor(), per_task.lower_factor())
     A = orc.reference_input(N)
@@ -147,9 +148,9 @@ def test_wave_level_execution_reports_the_per_task_statuses(cham):
     from dense_linear_app_amd.worker import DagCholeskyWorker
 
     B = 128
-    rng = np.random.default_rng(0)
 
     def run(batch: bool):
+        rng = np.random.default_rng(0)  # the same tiles in both runs
         plane = ak.ControlPlane(device_results=True, batch_ready=batch)
         w = DagCholeskyWorker()
         plane.register_worker("p", w)
@@ -182,4 +183,24 @@ def test_wave_level_execution_reports_the_per_task_statuses(cham):
     assert [o.details() for o in o1] == [o.details() for o in o2]
     assert o2[0].ok() and o2[4].ok() and not o2[1].ok() and not o2[2].ok() and not o2[3].ok()
     assert "Bad block size" in o2[1].details() and o2[2].details() == "Unknown op=NOPE" and "Missing dependency: missing-id" in o2[3].details()
-    assert g1 == g2 and w2.batched_tasks == 2
+    assert all(np.array_equal(np.frombuffer(a, dtype=np.float64), np.frombuffer(b, dtype=np.float64)) for a, b in zip(g1, g2))
+    assert w2.batched_tasks == 2
+
+
+def test_wave_level_execution_reports_a_failing_potrf_like_the_blocking_client(cham, orc):
+    """Wave-level mode enqueues the POTRF tasks too (chol_potrf_batch), so a tile that is not positive definite is
+    found out at the end of the run: the POTRF task then carries the reference's message (W2:243-244), its result
+    and everything computed from it are aborted, and the client's wait raises as the blocking client's does."""
+    from dense_linear_app_amd import armonik as ak, client
+
+    N, B = 1024, 256
+    A = orc.reference_input(N)
+    A[600, 600] = -5.0
+    with pytest.raises(ak.ResultNotAvailable, match="dpotrf info=89"):
+        client.run_cholesky_dag(N, B, A=A)
+    plane = ak.ControlPlane(device_results=True, batch_ready=True)
+    with pytest.raises(ak.ResultNotAvailable, match="dpotrf info=89"):
+        client.run_cholesky_dag(N, B, A=A, device_results=True, batched=True, plane=plane)
+    outs = [t.output.details() for t in plane._tasks.values() if t.status == "error"]
+    assert outs.count("Exception: [Worker][POTF] dpotrf info=89") == 1
+    assert all(o == "a data dependency was aborted" or "dpotrf info=89" in o for o in outs) and len(outs) > 1
