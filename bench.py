@@ -88,6 +88,12 @@ def load_pmc_traffic():
         return None
 
 
+def lib_counters() -> int:
+    from dense_linear_app_amd._lib import lib
+
+    return lib().chol_debug_device_counters()
+
+
 def run_single(a) -> dict:
     import torch
 
@@ -127,7 +133,8 @@ def run_single(a) -> dict:
     res = ch.residual_plgsy(d, float(N), a.seed) if not a.no_check else None
     ch.CHAMELEON_Desc_Destroy(d)
     return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
-            "residual": res, "probe": probe, "kernel": kernel, "calibration": ch.calibration()}
+            "residual": res, "probe": probe, "kernel": kernel, "calibration": ch.calibration(),
+            "counters": bool(lib_counters())}
 
 
 def run_multi(a) -> dict:
@@ -268,7 +275,9 @@ def main() -> int:
             }
             c = r["calibration"]
             line["config"]["schedule_calibration"] = {"mfma_probe_tflops": [round(c[0], 2), round(c[2], 2)],
-                                                      "diag_step_us": [round(c[1], 1), round(c[3], 1)]}
+                                                      "diag_step_us": [round(c[1], 1), round(c[3], 1)],
+                                                      # False: chol_init's probe left the counter-linked chain off (events only)
+                                                      "device_counters": r["counters"]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
             if a.cpu_extra_N and a.cpu_extra_N != a.cpu_N:

@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
         "chol_batch_info": ([i, C.POINTER(i)], i),
         "chol_debug_calibration": ([C.POINTER(d)], i),
         "chol_debug_update_kernel": ([i, C.c_char_p, i], i),
+        "chol_debug_device_counters": ([], i),
         "chol_dist_last_stats": ([C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i),
         "chol_dist_factorize_with": ([vp, vp, i, i, i, i, i, i], i),
         "chol_dist_gather_lower": ([vp, vp, i], i),

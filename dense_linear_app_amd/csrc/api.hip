@@ -641,6 +641,7 @@ int chol_init(int ncpu, int ngpu) {
   }
   if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
+  if (const char *e = getenv("CHOLMI_INTILE_FUSED_MAX")) cholmi::g_intile_fused_max = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
   if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);
   if (const char *e = getenv("CHOLMI_LATE_DMA")) cholmi::g_late_dma = atoi(e);
@@ -1397,6 +1398,11 @@ int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops) {
   std::lock_guard<std::mutex> lk(g_mu);
   return mfma_probe_on(&g.r, dtype, waves_per_simd, 4000, tflops);
 }
+
+// 1: the counter-linked form of chain-bound waves is available (chol_init's probe found the panel streams on
+// independent hardware queues and no device-side wait has timed out since); 0: every dependency is a stream
+// event -- the case under a profiler that serialises kernels (rocprofv3 --pmc), where the probe fails by design
+int chol_debug_device_counters(void) { return g.inited && g.r.d_sem ? 1 : 0; }
 
 int chol_debug_update_kernel(int dtype, char *buf, int buflen) {
   if (!buf || buflen < 8) return fail(-2, "debug_update_kernel: buffer");

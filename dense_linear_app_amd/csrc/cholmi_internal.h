@@ -118,6 +118,7 @@ extern int g_intile_small;
 extern int g_trsm_small_max;
 extern int g_poll_max_wgs;
 extern int g_intile_fused;
+extern int g_intile_fused_max;
 extern int g_min_units;
 extern int g_trsm_fused_min;
 extern int g_late_dma;

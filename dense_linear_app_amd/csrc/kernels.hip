@@ -2398,6 +2398,7 @@ int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four wave
 int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
+int g_intile_fused_max = 256;  // ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3 (nr <= 10); beyond, resident pollers would queue for CU slots behind each other (CHOLMI_INTILE_FUSED_MAX)
 int g_poll_max_wgs = 48;  // grids up to this many workgroups poll their counter themselves, larger ones behind a gate (CHOLMI_POLL_MAX_WGS)
 int g_trsm_small_max = 64;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
@@ -2517,7 +2518,7 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
     const int nr = nbm - 1 - st;
     if (nr > 0) {
       // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
-      if (fused_steps) {
+      if (fused_steps && nr * (2 * nr + 1) <= g_intile_fused_max) {
         k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, s>>>(tile, mb, nbm, st, winv, g_ytab, sem + 32 * st, d_info);
       } else if (g_intile_small) {
         k_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, 0, mb, nbm, st + 1, st, winv, T(1), g_ytab);
@@ -2584,7 +2585,7 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                        wait_target, pipe ? slot(s) : nullptr);
     if (nr > 0) {
       if (g_intile_small) {
-        if (pipe && g_intile_fused) {
+        if (pipe && g_intile_fused && nr * (2 * nr + 1) <= g_intile_fused_max) {
           // solve and update of the step in one launch, the update's workgroups polling the solves' counter
           // (which the TRSM step's update on st polls too)
           k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab, slot(nbm + s),

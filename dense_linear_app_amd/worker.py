@@ -210,7 +210,15 @@ class DagCholeskyWorker(ArmoniKWorker):
         if self.verbose:
             print(f"[PERF] op={op} time={secs} sec flops={flops} gflops={self.last_perf['gflops']}", file=self.log)
 
-    def Execute(self, taskHandler: TaskHandler) -> ProcessStatus:  # noqa: N802, C901
+    def Execute(self, taskHandler: TaskHandler) -> ProcessStatus:  # noqa: N802
+        """W2:99-564.  Tasks whose tiles are HBM-resident take the grouped-launch path with a group of one (no
+        private torch copy, no stream hand-over, no descriptors: chol_tile_batch does the copy and the kernel);
+        everything else -- host blobs, POTRF, odd tile sizes, any task that fails a check -- is _execute_one."""
+        if self._tags:
+            return self.ExecuteBatch([taskHandler])[0]
+        return self._execute_one(taskHandler)
+
+    def _execute_one(self, taskHandler: TaskHandler) -> ProcessStatus:  # noqa: C901
         try:
             payload = taskHandler.getPayload()
             if self.verbose:
@@ -348,7 +356,7 @@ class DagCholeskyWorker(ArmoniKWorker):
         n = len(handlers)
         out: list = [None] * n
         if not isinstance(self.backend, HipTileBackend):
-            return [self.Execute(h) for h in handlers]
+            return [self._execute_one(h) for h in handlers]
         groups: dict = {}
         for idx, h in enumerate(handlers):
             try:
@@ -357,7 +365,7 @@ class DagCholeskyWorker(ArmoniKWorker):
                 if code is None and p.op == "POTRF" and self.async_potrf:
                     code = 4
                 if code is None or p.B <= 0 or p.B % 128:
-                    out[idx] = self.Execute(h)
+                    out[idx] = self._execute_one(h)
                     continue
                 names = ((p.inA, p.inL) if code == 1 else (p.inC, p.inA) if code == 2 else (p.inC, p.inAi, p.inAj) if code == 3
                          else (p.in_,))
@@ -365,7 +373,7 @@ class DagCholeskyWorker(ArmoniKWorker):
                 blobs = [deps.get(x) for x in names]
                 want = p.B * p.B * 8
                 if any(not isinstance(b, DeviceBlob) or b.nbytes != want for b in blobs):
-                    out[idx] = self.Execute(h)  # (missing / short / host blobs: the per-task path reports them)
+                    out[idx] = self._execute_one(h)  # (missing / short / host blobs: the one-task path reports them)
                     continue
                 groups.setdefault((code, p.B), []).append((idx, h, blobs, _tag_of(p.inL) if code == 1 else 0))
             except Exception as e:  # W2:558-560

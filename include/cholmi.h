@@ -237,6 +237,10 @@ int chol_debug_calibration(double *out8);
 /* Name of the trailing-update kernel launched for `dtype` under the current CHOLMI_VARIANT / CHOLMI_F32_W8
  * switches, as a profiler prints it (bench.py's roofline.kernel). */
 int chol_debug_update_kernel(int dtype, char *buf, int buflen);
+/* 1 if chain-bound waves can use device-side counters (chol_init's probe found the panel streams on independent
+ * hardware queues, and no device-side wait has timed out since), 0 if every dependency is a stream event -- e.g.
+ * under a profiler that serialises kernels, where the probe fails by design. */
+int chol_debug_device_counters(void);
 
 /* ---- local storage of a descriptor ---------------------------------------- */
 void *chol_desc_local_ptr(chol_desc_t *desc, size_t *bytes);

@@ -307,3 +307,33 @@ def test_v3_long_option_driver(cham, orc):
     assert re.search(r"^N=2048 NB=256 ncpu=1 ngpu=1 p=1 q=1 bump=2048 uplo=121 seed=51$", r.stdout, re.M), r.stdout
     r = subprocess.run([exe] + args()[:-2], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "all options are required" in r.stderr
+
+
+def test_desc_version_tag_reuses_the_block_inverses_of_the_factored_tile(cham, orc):
+    """chol_desc_set_version: POTRF on a tagged in-place device tile keeps the tile's block inverses; TRSM with an L of
+    the same buffer AND tag uses them, any other tag (or none) recomputes them from L -- same solution to rounding."""
+    import torch
+
+    ch = cham
+    B = 512
+    A = orc.reference_input(B)
+    rng = np.random.default_rng(3)
+    X0 = np.asfortranarray(rng.standard_normal((B, B)))
+    dl = torch.from_numpy(A.ravel(order="F").copy()).cuda()
+    dL = ch.CHAMELEON_Desc_Create(dl, ch.ChamRealDouble, B, B, B * B, B, B, 0, 0, B, B, 1, 1)
+    dL.set_version(0x1234abcd)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, dL) == 0
+    outs = []
+    for tag in (0x1234abcd, 0x777, 0):
+        dx = torch.from_numpy(X0.ravel(order="F").copy()).cuda()
+        dX = ch.CHAMELEON_Desc_Create(dx, ch.ChamRealDouble, B, B, B * B, B, B, 0, 0, B, B, 1, 1)
+        dL.set_version(tag)
+        assert ch.CHAMELEON_dtrsm_Tile(ch.ChamRight, ch.ChamLower, ch.ChamTrans, ch.ChamNonUnit, 1.0, dL, dX) == 0
+        outs.append(dx.cpu().numpy().reshape((B, B), order="F").copy())
+        ch.CHAMELEON_Desc_Destroy(dX)
+    L = np.tril(dl.cpu().numpy().reshape((B, B), order="F"))
+    ref = orc.dtrsm(L, X0)
+    for o in outs:
+        assert np.abs(o - ref).max() <= 16 * B * 2.0 ** -52 * np.abs(ref).max()
+    assert np.array_equal(outs[1], outs[2])  # both recomputed from L
+    ch.CHAMELEON_Desc_Destroy(dL)
