@@ -150,10 +150,7 @@ void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 
 // POTRF(tile) on stream sp with the TRSM of `ntiles` contiguous tiles pipelined behind it on
 // stream st (ev: mb/MACRO + 1 events).  ev_head (may be null): recorded once the FIRST panel tile is
-// solved (a long panel's other tiles follow in one throughput-form launch).  chain: the head tile's last
-// TRSM step runs on sp itself (no cross-stream hop on the critical chain); st is made to wait for it, so an
-// event the caller records on st afterwards stands for the whole panel.  ev_col (chain mode): the event behind which
-// the panel's tiles carry every earlier update -- what st has been made to wait for by the caller.
+// solved (a long panel's other tiles follow in one throughput-form launch).
 // chol_init's probe: the consumer kernel goes first, polls *sem (zeroed) for <= ~20 ms and writes 1 (seen) or
 // 2 (gave up) to *result; the producer kernel raises *sem
 void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result);
@@ -174,8 +171,8 @@ struct SyrkPipe {
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles,
-                            hipEvent_t ev_head = nullptr, bool chain = false, hipEvent_t ev_col = nullptr,
-                            const SyrkPipe *sy = nullptr, const int *wait_sem = nullptr, int wait_target = 0);
+                            hipEvent_t ev_head = nullptr, const SyrkPipe *sy = nullptr, const int *wait_sem = nullptr,
+                            int wait_target = 0);
 
 // winv from an already factored tile
 template <typename T>

@@ -132,7 +132,7 @@ struct HipOps {
             const int *wait_sem, int wait_target) {
     launch_panel_pipelined<T>(r.st[ST_PANEL], r.st[ST_TRSM], &r.events[ev_steps], (T *)lkk, g.mb, (T *)wv, r.d_info,
                               k * g.mb, (T *)tiles, (long)g.mb * g.mb, ntiles, ev_head >= 0 ? r.events[ev_head] : nullptr,
-                              false, nullptr, sy, wait_sem, wait_target);
+                              sy, wait_sem, wait_target);
     return launched();
   }
   int trsm(int, char *tiles, int ntiles, const char *lkk, const char *wv, int st) {

@@ -2564,17 +2564,12 @@ void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
-                            bool chain, hipEvent_t ev_col, const SyrkPipe *sy, const int *wait_sem,
-                            int wait_target) {
+                            const SyrkPipe *sy, const int *wait_sem, int wait_target) {
   const int nbm = mb / MACRO;
   const bool fused = trsm_fused_applies<T>(ntiles - 1, mb);
   // (SyrkPipe needs the step-by-step TRSM of the whole panel; the walker does not combine it with the fused form)
-  const bool pipe = sy && !fused && !chain && ntiles > 0;
+  const bool pipe = sy && !fused && ntiles > 0;
   const int nstep = fused ? 1 : ntiles;  // tiles that follow the POTRF step by step
-  // chain: the wave is as long as its panel chain (late waves, small matrices).  A dependency that
-  // crosses streams costs 14-19 us of wake-up latency where one inside a stream costs ~1 us, so the
-  // chain's own work -- the head tile's last TRSM step (the earlier ones ran beside the POTRF) -- stays
-  // on sp; the caller does the same with the SYRK on the next diagonal tile.
   // pipe: counters of this wave, one 128-byte slot each -- D[s] the diagonal-block step s, I[s] the in-tile
   // solve of step s (4 nr workgroups), H[s] the head tile's workgroups of TRSM step s, then `done`
   auto slot = [&](int i) { return sy->sem + 32 * i; };
@@ -2627,33 +2622,16 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
     // (recorded behind the in-tile update, not between the solve and the update: an event record
     // between two dependent launches of the chain costs it ~7 us, the TRSM step loses nothing)
     (void)hipEventRecord(ev[s], sp);
-    if (chain && s == nbm - 1) {
-      // the head tile's earlier steps (on st, which waited for the panel's column to be up to date);
-      // with one step per tile sp itself must wait for that column: ev_col
-      if (nbm > 1)
-        (void)hipStreamWaitEvent(sp, ev[nbm], 0);
-      else if (ev_col)
-        (void)hipStreamWaitEvent(sp, ev_col, 0);
-      trsm_step<T>(sp, tiles, bsiz, 1, lkk, winv, mb, s, T(1));
-      if (ev_head) (void)hipEventRecord(ev_head, sp);
-      (void)hipStreamWaitEvent(st, ev[s], 0);
-      if (nstep > 1) trsm_step<T>(st, tiles + bsiz, bsiz, nstep - 1, lkk, winv, mb, s, T(1));
-      if (ev_head) (void)hipStreamWaitEvent(st, ev_head, 0);  // what the caller records on st next covers the head tile
-    } else {
-      (void)hipStreamWaitEvent(st, ev[s], 0);
-      trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
-      if (chain && s == nbm - 2) (void)hipEventRecord(ev[nbm], st);
-    }
+    (void)hipStreamWaitEvent(st, ev[s], 0);
+    trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
   }
-  if (ev_head && !(chain && ntiles > 0)) (void)hipEventRecord(ev_head, st);
+  if (ev_head) (void)hipEventRecord(ev_head, st);
   if (fused) launch_trsm_fused<T>(st, tiles + bsiz, bsiz, ntiles - 1, lkk, winv, mb);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
-                                             int *, int, double *, long, int, hipEvent_t, bool, hipEvent_t,
-                                             const SyrkPipe *, const int *, int);
+                                             int *, int, double *, long, int, hipEvent_t, const SyrkPipe *, const int *, int);
 template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
-                                            int, float *, long, int, hipEvent_t, bool, hipEvent_t, const SyrkPipe *,
-                                            const int *, int);
+                                            int, float *, long, int, hipEvent_t, const SyrkPipe *, const int *, int);
 
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {
