@@ -205,6 +205,13 @@ def run_multi(a) -> dict:
     t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     stats = dd.dist_last_stats()
+    # device time of each rank's own schedule in the last step (HIP events on its streams): max and min over ranks --
+    # their spread is the block-cyclic imbalance plus what each rank waited for tiles
+    dev = torch.tensor([ch.last_potrf_stats()["total_ms"]], dtype=torch.float64)
+    dmax, dmin = dev.clone(), dev.clone()
+    dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+    stats["device_ms_max"], stats["device_ms_min"] = round(float(dmax.item()), 3), round(float(dmin.item()), 3)
     # the factor of the last timed step, gathered on rank 0 and checked (untimed) against the regenerated matrix
     res = None
     if not a.no_check:
@@ -286,7 +293,8 @@ def main() -> int:
         line["residual"] = r["residual"]
     if r.get("dist"):
         line["config"]["exchange"] = {"backend": r["backend"], "fallback": r.get("fallback"), "host_issue_us_per_wave": round(r["dist"]["issue_us_per_wave"], 1),
-                                      "sends_per_rank0": r["dist"]["sends"], "bytes_sent_rank0": r["dist"]["bytes_sent"]}
+                                      "sends_per_rank0": r["dist"]["sends"], "bytes_sent_rank0": r["dist"]["bytes_sent"],
+                                      "rank_device_ms_last_step": [r["dist"]["device_ms_min"], r["dist"]["device_ms_max"]]}
     print(json.dumps(line), flush=True)
     return 0
 

@@ -1,7 +1,10 @@
-"""The distributed driver on real kernels: HipEngine + libcholmi wave kernels with P x Q > 1.
-Only one GPU is available to the tests, so the ranks share cuda:0 and the broadcasts go
-through gloo (RCCL needs one GPU per rank); ownership, local indexing, panel addressing and
-stream ordering are exactly the multi-GPU code path."""
+"""The p x q walker on real kernels with P x Q > 1, on the one GPU a test box has:
+  * chol_dist_rehearse: the ranks are THREADS of this process, each with its own streams and workspaces, tiles moved by
+    stream-ordered device copies -- nothing ever synchronises the device, so the stream / event ordering and the rotation
+    of the receive buffers are what is tested;
+  * chol_potrf_tile on a p x q descriptor with the ranks as PROCESSES sharing cuda:0 and a gloo transport table (RCCL
+    wants one GPU per rank): the C ABI path end to end, gather and residual included;
+  * the RCCL transport itself: version check, two one-rank communicators, a tile to self on each channel."""
 import os
 import socket
 import sys
