@@ -337,3 +337,74 @@ def test_desc_version_tag_reuses_the_block_inverses_of_the_factored_tile(cham, o
         assert np.abs(o - ref).max() <= 16 * B * 2.0 ** -52 * np.abs(ref).max()
     assert np.array_equal(outs[1], outs[2])  # both recomputed from L
     ch.CHAMELEON_Desc_Destroy(dL)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_tile_batches_through_the_raw_abi(cham, dtype):
+    """chol_potrf_batch / chol_tile_batch on lists of device pointers, both precisions, several tasks per call:
+    every task equals the numpy result of the same operation, inputs are left untouched (private copies), a tile
+    that is not positive definite reports its own info and leaves the others alone."""
+    import torch
+
+    from dense_linear_app_amd._lib import lib
+
+    ch, L = cham, lib()
+    B, n = 256, 3
+    npdt, tdt, cdt = (np.float64, torch.float64, ch.ChamRealDouble) if dtype == "f64" else (np.float32, torch.float32, ch.ChamRealFloat)
+    tol = 1e-12 if dtype == "f64" else 2e-4
+    rng = np.random.default_rng(5)
+
+    def dev(a):
+        return torch.from_numpy(np.asfortranarray(a).ravel(order="F").copy()).cuda()
+
+    def host(t):
+        return t.cpu().numpy().reshape((B, B), order="F").astype(np.float64)
+
+    def ptrs(ts):
+        return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    spd = []
+    for q in range(n):
+        M = rng.standard_normal((B, B))
+        spd.append((M @ M.T + B * np.eye(B)).astype(npdt))
+    spd[1][7, 7] = -1.0  # task 1 is not positive definite
+    a_in = [dev(a) for a in spd]
+    a_out = [torch.zeros(B * B, dtype=tdt, device="cuda") for _ in range(n)]
+    slots = (C.c_int * n)()
+    assert L.chol_potrf_batch(cdt, B, n, ptrs(a_in), ptrs(a_out), None, slots, 1) == 0, L.chol_last_error()
+    infos = []
+    for q in range(n):
+        v = C.c_int()
+        assert L.chol_batch_info(slots[q], C.byref(v)) == 0
+        infos.append(v.value)
+    assert infos == [0, 8, 0]
+    for q in (0, 2):
+        Lq = np.tril(host(a_out[q]))
+        A = spd[q].astype(np.float64)
+        assert np.linalg.norm(Lq @ Lq.T - A) / np.linalg.norm(A) <= (1e-14 if dtype == "f64" else 1e-5)
+        assert np.array_equal(host(a_in[q]), A)  # the input was copied, not factored in place
+    # TRSM / SYRK / GEMM: three tasks each
+    Lt = [np.tril(host(a_out[0])).astype(npdt)] * n
+    Cs = [rng.standard_normal((B, B)).astype(npdt) for _ in range(n)]
+    As = [rng.standard_normal((B, B)).astype(npdt) for _ in range(n)]
+    Bs = [rng.standard_normal((B, B)).astype(npdt) for _ in range(n)]
+    dC, dA, dB, dL = [dev(c) for c in Cs], [dev(a) for a in As], [dev(b) for b in Bs], [dev(Lt[0])] * n
+    out = torch.zeros(n * B * B, dtype=tdt, device="cuda")
+    outs = [out[q * B * B:(q + 1) * B * B] for q in range(n)]
+    for code, a_list, b_list in ((1, dL, None), (2, dA, None), (3, dA, dB)):
+        out.zero_()
+        rc = L.chol_tile_batch(code, cdt, B, n, ptrs(dC), ptrs(a_list), ptrs(b_list) if b_list else None, ptrs(outs), None, 0)
+        assert rc == 0, L.chol_last_error()
+        for q in range(n):
+            got, Cq, Aq, Bq = host(outs[q]), Cs[q].astype(np.float64), As[q].astype(np.float64), Bs[q].astype(np.float64)
+            if code == 1:
+                ref = np.linalg.solve(Lt[0].astype(np.float64), Cq.T).T  # X L^T = C
+            elif code == 2:
+                ref = Cq - Aq @ Aq.T
+                ref[np.triu_indices(B, 1)] = Cq[np.triu_indices(B, 1)]  # strict upper triangle: the copy
+            else:
+                ref = Cq - Aq @ Bq.T
+            assert np.abs(got - ref).max() <= tol * B * max(1.0, np.abs(ref).max()), (code, q)
+            assert np.array_equal(host(dC[q]), Cq)
+    assert L.chol_tile_batch(9, cdt, B, n, ptrs(dC), ptrs(dA), None, ptrs(outs), None, 0) < 0
+    assert L.chol_tile_batch(3, cdt, 100, n, ptrs(dC), ptrs(dA), ptrs(dB), ptrs(outs), None, 0) == -104
