@@ -227,6 +227,28 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
   return r;
 }
 
+// ---- sub-matrix views over a user buffer: the library works on a compact image of the view's tiles
+int view_sync(chol_desc *d, bool in) {
+  const size_t tb = (size_t)d->bsizi * d->esize;
+  for (int J = 0; J < d->nt; ++J) {
+    char *user = reinterpret_cast<char *>(d->user_mat) + ((size_t)d->user_oi + (size_t)(J + d->user_oj) * d->user_lmt) * tb;
+    char *img = reinterpret_cast<char *>(d->mat) + (size_t)J * d->lmt * tb;
+    HIPCHECK(hipMemcpy(in ? img : user, in ? user : img, (size_t)d->mt * tb, hipMemcpyDefault));
+  }
+  return 0;
+}
+struct ViewSync {
+  chol_desc *d;
+  bool out;
+  int rc = 0;
+  ViewSync(chol_desc *dd, bool write_back) : d(dd && dd->user_mat ? dd : nullptr), out(write_back) {
+    if (d) rc = view_sync(d, true);
+  }
+  ~ViewSync() {
+    if (d && out && rc == 0) (void)view_sync(d, false);
+  }
+};
+
 int build_worklist(chol_desc *d) {
   if (d->mt != d->nt) return 0;  // only square tile grids are factored
   std::vector<int2> off, dg;
@@ -713,6 +735,8 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
   if (p <= 0 || p > MAXP) return fail(-13, "desc_create: p");
   if (q <= 0) return fail(-14, "desc_create: q");
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "desc_create before chol_init");
+  void *view_user = nullptr;
+  int view_lmt = 0, view_oi = 0, view_oj = 0;
   if (i != 0 || j != 0 || m != lm || n != ln) {
     // A sub-matrix view A(i:i+m, j:j+n) of an lm x ln matrix (V6:24-25, 44-45 pass ioff, joff, m, n
     // straight through).  With library-owned storage nothing outside the view can ever be observed
@@ -720,9 +744,19 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
     // view coordinates (dplgsy: entry (r, c) of the view, order m) -- so the view IS an m x n matrix of
     // its own: only the tiles it can address are allocated.  Tile-aligned offsets only (an unaligned
     // view starts with a partial tile, which would change what tile (0,0) means to tile_upload / _download).
-    if (mat) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views (i,j,m,n) over a user buffer are not supported");
     if (i % mb || j % nb) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views need tile-aligned offsets (i % mb == 0, j % nb == 0)");
     if (p * q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views of distributed matrices are not supported");
+    if (mat) {
+      // over a user buffer (v3's --mat user with offsets): the user's matrix is lm x ln in whole mb x nb tiles; the
+      // library keeps a compact image of the view's tiles and mirrors it around every operation (ViewSync)
+      if (lm % mb || ln % nb || m % mb || n % nb || mb != nb)
+        return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: a view over a user buffer needs whole square tiles (lm, ln, m, n multiples of mb = nb)");
+      view_user = mat;
+      view_lmt = lm / mb;
+      view_oi = i / mb;
+      view_oj = j / nb;
+      mat = nullptr;
+    }
     lm = m;
     ln = n;
     i = j = 0;
@@ -795,6 +829,10 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
       return rc;
     }
   }
+  d->user_mat = view_user;
+  d->user_lmt = view_lmt;
+  d->user_oi = view_oi;
+  d->user_oj = view_oj;
   *desc = d;
   return 0;
 }
@@ -956,6 +994,7 @@ int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, c
 
 // ---------------------------------------------------------------- POTRF
 int chol_potrf_tile(int uplo, chol_desc_t *A) {
+  ViewSync vsA(A, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrf_tile: uplo");
   if (!A) return fail(-2, "potrf_tile: NULL descriptor");
@@ -985,6 +1024,7 @@ int chol_potrf_tile(int uplo, chol_desc_t *A) {
 
 int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_desc_t *A,
                    chol_desc_t *B) {
+  ViewSync vsA(A, false), vsB(B, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "trsm_tile before chol_init");
   if (side != CHOL_LEFT && side != CHOL_RIGHT) return fail(-1, "trsm_tile: side");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-2, "trsm_tile: uplo");
@@ -1002,6 +1042,7 @@ int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_d
 
 // ---------------------------------------------------------------- SYRK / GEMM
 int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *C) {
+  ViewSync vsA(A, false), vsC(C, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "syrk_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "syrk_tile: uplo");
   if (trans != CHOL_NOTRANS && trans != CHOL_TRANS) return fail(-2, "syrk_tile: trans");
@@ -1018,6 +1059,7 @@ int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double bet
 
 int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
                    double beta, chol_desc_t *C) {
+  ViewSync vsA(A, false), vsB(B, false), vsC(C, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "gemm_tile before chol_init");
   if (transA != CHOL_NOTRANS && transA != CHOL_TRANS) return fail(-1, "gemm_tile: transA");
   if (transB != CHOL_NOTRANS && transB != CHOL_TRANS) return fail(-2, "gemm_tile: transB");
@@ -1036,6 +1078,7 @@ int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_de
 
 // ---------------------------------------------------------------- generator / layout / residual
 int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed) {
+  ViewSync vsA(A, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "plgsy_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-2, "plgsy_tile: uplo");
   const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
@@ -1081,6 +1124,7 @@ static TileGeo geo_of(const chol_desc *d) {
 }
 
 int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
+  ViewSync vsA(A, false), vsB(B, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lacpy_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-1, "lacpy_tile: uplo");
   int rc = resident_whole("lacpy_tile", A);
@@ -1099,6 +1143,7 @@ int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
 }
 
 int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *B) {
+  ViewSync vsA(A, false), vsB(B, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "geadd_tile before chol_init");
   if (trans != CHOL_NOTRANS) return fail(CHOL_ERR_NOT_SUPPORTED, "geadd_tile: only ChamNoTrans (V6:83)");
   int rc = resident_whole("geadd_tile", A);
@@ -1116,6 +1161,7 @@ int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_d
 }
 
 int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
+  ViewSync vsA(A, false);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lange_tile before chol_init");
   if (!value) return fail(-3, "lange_tile: NULL value");
   int kind;
@@ -1146,6 +1192,7 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
 }
 
 int chol_lauum_tile(int uplo, chol_desc_t *A) {
+  ViewSync vsA(A, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lauum_tile before chol_init");
   if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "lauum_tile: only ChamLower (V6:80)");
   int rc = resident_whole("lauum_tile", A);
@@ -1179,6 +1226,7 @@ int chol_lauum_tile(int uplo, chol_desc_t *A) {
 
 // ---------------------------------------------------------------- solve with the factor
 int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
+  ViewSync vsA(A, false), vsB(B, true);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrs_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrs_tile: uplo");
   int rc = resident_whole("potrs_tile", A);
@@ -1220,6 +1268,7 @@ static inline int tile_rows(const chol_desc *d, int I) { return std::min(d->mb, 
 static inline int tile_cols(const chol_desc *d, int J) { return std::min(d->nb, d->ln - J * d->nb); }
 
 int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
+  ViewSync vs(d, true);
   if (!d || !host_tile) return fail(-1, "tile_upload: NULL");
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_upload: tile not owned by this process");
@@ -1232,6 +1281,7 @@ int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
 }
 
 int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
+  ViewSync vs(d, false);
   if (!d || !host_tile) return fail(-1, "tile_download: NULL");
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_download: tile not owned by this process");
@@ -1244,6 +1294,7 @@ int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
 }
 
 int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
+  ViewSync vs(d, true);
   if (!A || !d) return fail(-1, "lapack_to_tile: NULL");
   if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "lapack_to_tile: single-process descriptors only");
   if (lda < d->lm) return fail(-2, "lapack_to_tile: lda");
@@ -1258,6 +1309,7 @@ int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
 }
 
 int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
+  ViewSync vs(d, false);
   if (!A || !d) return fail(-1, "tile_to_lapack: NULL");
   if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_to_lapack: single-process descriptors only");
   if (lda < d->lm) return fail(-3, "tile_to_lapack: lda");
@@ -1273,6 +1325,7 @@ int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
 
 static int residual_common(chol_desc_t *L, double bump, unsigned long long seed, double *rel_fro,
                            double *rel_inf) {
+  ViewSync vsL(L, false);
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "residual before chol_init");
   if (!L || (!rel_fro && !rel_inf)) return fail(-1, "residual: NULL");
   if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mbi % MACRO)

@@ -30,6 +30,11 @@ struct chol_desc {
   // chol_desc_set_version: names the CONTENT behind `mat` (the worker: a hash of the write-once result id the
   // blob belongs to); lets the library keep the block inverses of a factored tile for the TRSM tasks that follow
   unsigned long long version = 0;
+  // A sub-matrix view (i, j, m, n) over a USER buffer (tile-aligned offsets, whole tiles): `mat` is a library-owned
+  // compact image of the view's tiles, refreshed from the user's tile matrix before every operation on this
+  // descriptor and written back after every operation that modifies it (api.hip: ViewSync).
+  void *user_mat = nullptr;
+  int user_lmt = 0, user_oi = 0, user_oj = 0;  // the user's tile grid (rows) and the view's first tile in it
 };
 
 extern "C" int chol_internal_fail(int code, const char *msg);  // api.hip: sets chol_last_error, returns code

@@ -260,7 +260,8 @@ def v3_test(argv: Sequence[str], out=sys.stdout, err=sys.stderr) -> int:
     try:
         # bsiz goes straight through, as in the reference (v3:212); the library refuses bsiz != mb*nb with its own message
         descA = ch.CHAMELEON_Desc_Create(mat, dtyp, mb, nb, bsiz, lm, ln, ioff, joff, m, n, p, q)
-        if mat is None:
+        view = (ioff, joff, m, n) != (0, 0, lm, ln)
+        if mat is None or view:  # (a view over the user buffer is mirrored through a device image: generate in place)
             ch.CHAMELEON_dplgsy_Tile(bump, uplo, descA, seed)
         else:  # the generator runs on the device: fill a resident twin, bring the tiles to the host buffer
             twin = ch.CHAMELEON_Desc_Create(None, dtyp, mb, nb, mb * nb, lm, ln, ioff, joff, m, n, p, q)

@@ -259,8 +259,9 @@ def test_submatrix_views_on_library_owned_descriptors(cham, orc):
     assert ch.residual_plgsy(d2, 616.0, 7) <= 1e-13
     with pytest.raises(ch.CholmiError, match="tile-aligned"):
         ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, 100, 0, m, m, 1, 1)
+    # over a user buffer a view needs whole tiles (test_sub_matrix_view_over_a_user_buffer covers the served case)
     with pytest.raises(ch.CholmiError, match="user buffer"):
-        ch.CHAMELEON_Desc_Create(np.zeros(lm * lm), ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, i0, i0, m, m, 1, 1)
+        ch.CHAMELEON_Desc_Create(np.zeros(2000 * 2000), ch.ChamRealDouble, mb, mb, mb * mb, 2000, 2000, i0, i0, m, m, 1, 1)
 
 
 def test_v3_long_option_driver(cham, orc):
@@ -284,7 +285,7 @@ def test_v3_long_option_driver(cham, orc):
         return out
 
     for kw in ({}, {"uplo": "U"}, {"dtyp": "s"}, {"i": 512, "j": 512, "m": 1024, "n": 1024, "bump": 1024},
-               {"mat": "user"}):
+               {"mat": "user"}, {"mat": "user", "i": 512, "j": 256, "m": 1024, "n": 1024, "bump": 1024}):
         out, err = io.StringIO(), io.StringIO()
         assert driver.v3_test(args(**kw), out=out, err=err) == 0, err.getvalue()
         text = out.getvalue()
@@ -408,3 +409,43 @@ def test_tile_batches_through_the_raw_abi(cham, dtype):
             assert np.array_equal(host(dC[q]), Cq)
     assert L.chol_tile_batch(9, cdt, B, n, ptrs(dC), ptrs(dA), None, ptrs(outs), None, 0) < 0
     assert L.chol_tile_batch(3, cdt, 100, n, ptrs(dC), ptrs(dA), ptrs(dB), ptrs(outs), None, 0) == -104
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_sub_matrix_view_over_a_user_buffer(cham, orc, where):
+    """CHAMELEON_Desc_Create(mat != NULL, ..., i, j, m, n): a tile-aligned view of the user's tile matrix (v3 driver:
+    --mat user with offsets).  The library mirrors the view through a device image: the view's tiles are factored in
+    the user's buffer, every other tile of it stays bit for bit what it was."""
+    import torch
+
+    ch = cham
+    mb, lt, oi, oj, vt = 256, 5, 1, 2, 3  # user matrix: 5 x 5 tiles; view: 3 x 3 tiles starting at tile (1, 2)
+    lm = lt * mb
+    m = vt * mb
+    rng = np.random.default_rng(9)
+    user = rng.standard_normal(lt * lt * mb * mb)  # tile layout, every tile noise
+    A = orc.plgsy_matrix(m, float(m), 7)
+    buf = user.copy() if where == "host" else torch.from_numpy(user.copy()).cuda()
+    d = ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, oi * mb, oj * mb, m, m, 1, 1)
+    d.from_lapack(A)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(d.to_lapack())
+    Lref, info = orc.cholesky_lower(A, mb)
+    assert info == 0 and np.abs(L - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    now = (buf if where == "host" else buf.cpu().numpy()).reshape(lt * lt, mb * mb)
+    before = user.reshape(lt * lt, mb * mb)
+    for J in range(lt):
+        for I in range(lt):
+            inside = oi <= I < oi + vt and oj <= J < oj + vt
+            t = now[I + J * lt]
+            if not inside:
+                assert np.array_equal(t, before[I + J * lt]), (I, J)
+            elif I - oi >= J - oj:  # a lower tile of the view: holds the factor
+                ref = Lref[(I - oi) * mb:(I - oi + 1) * mb, (J - oj) * mb:(J - oj + 1) * mb]
+                got = t.reshape((mb, mb), order="F")
+                got = np.tril(got) if I - oi == J - oj else got
+                assert np.abs(got - ref).max() <= 1e-12 * np.abs(Lref).max(), (I, J)
+    ch.CHAMELEON_Desc_Destroy(d)
+    # unaligned offsets stay refused
+    with pytest.raises(ch.CholmiError, match="tile-aligned"):
+        ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, 100, 0, m, m, 1, 1)
