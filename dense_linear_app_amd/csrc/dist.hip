@@ -501,6 +501,8 @@ int walk_t(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool re
 
 int walk_with(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool reset_ytab) {
   if (d->mt != d->nt || d->lm != d->ln) return chol_internal_fail(-2, "potrf_tile: matrix is not square");
+  if ((int)d->ge.size() < d->nt + 2)  // (a one-tile matrix on a p x q grid: no work list was built for it)
+    return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "potrf_tile: a distributed descriptor needs more than one tile");
   if (d->p * d->q > 1) {
     if (!d->on_device) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: the local tiles must be device-resident");
     if (d->mbi % MACRO) return chol_internal_fail(CHOL_ERR_NOT_SUPPORTED, "distributed potrf: stored tile edge must be a multiple of 128");
