@@ -4,6 +4,8 @@ reference's metric, v6_test.c:60) on N MI355X of one node.
 
   python bench.py --gpus 1 --steps K --warmup W            (default: N=65536, tile=1024, fp64)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 ...
+  python bench.py --gpus 8 ...      (no launcher: this process starts and supervises the 8 ranks itself and
+                                     never touches a GPU; see launch_ranks)
 
 A step is one factorisation of a freshly generated matrix that is already resident in HBM
 in tile layout; every step is timed in its own synchronised bracket and the K brackets are
@@ -17,7 +19,12 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,7 +51,23 @@ def parse():
     ap.add_argument("--cpu-extra-N", type=int, default=20480)
     ap.add_argument("--no-check", action="store_true",
                     help="skip the (untimed) residual of the last step's factor; by default it is in the line")
+    ap.add_argument("--stall-timeout", type=float, default=600.0,
+                    help="self-launched ranks (--gpus N without a launcher): seconds without a heartbeat from any rank "
+                         "after which the run is declared hung, the ranks are killed and an error line is printed")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------- heartbeat of a supervised rank
+def beat(tag: str) -> None:
+    """A rank started by launch_ranks says where it is (one small file per rank; the parent watches the mtimes)."""
+    d = os.environ.get("CHOLMI_BENCH_HB")
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}"), "w") as f:
+            f.write(f"{tag} {time.time():.3f}\n")
+    except OSError:
+        pass
 
 
 def cpu_baseline(N: int, B: int, seed: int, vendor: bool = True) -> dict:
@@ -129,12 +152,21 @@ def run_single(a) -> dict:
         upd_flops += st["update_flops"]
         upd_launches += st["update_launches"]
     ch.set_profiling(False)
-    # the factor the last timed step left in HBM, checked (untimed) against the regenerated matrix
+    # one step more, outside the K timed ones, WITHOUT the library's brackets: what the event records and the closing
+    # waits of the profiled steps cost (they add no dependency; this puts the number on record)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, a.seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
+    torch.cuda.synchronize()
+    unprofiled = time.perf_counter() - t0
+    assert info == 0, info
+    # the factor the last step left in HBM (same matrix, same schedule as the timed ones), checked (untimed)
     res = ch.residual_plgsy(d, float(N), a.seed) if not a.no_check else None
     ch.CHAMELEON_Desc_Destroy(d)
     return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
             "residual": res, "probe": probe, "kernel": kernel, "calibration": ch.calibration(),
-            "counters": bool(lib_counters())}
+            "counters": bool(lib_counters()), "unprofiled_ms": unprofiled * 1e3}
 
 
 def run_multi(a) -> dict:
@@ -160,7 +192,9 @@ def run_multi(a) -> dict:
     assert backend in ("rccl", "gloo"), backend
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
+    beat("init")
     dist.init_process_group("gloo")
+    beat("rendezvous")
     P, Q = dd.grid_for(world)
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
     fallback = None
@@ -190,6 +224,9 @@ def run_multi(a) -> dict:
         eng.generate(float(a.N), a.seed)
         info = factor()
         assert info == 0, info
+        beat(f"warmup{w}")
+    if os.environ.get("CHOLMI_BENCH_KILL_RANK") == str(rank):  # test switch: this rank dies between warm-up and timing
+        os._exit(17)
     elapsed = 0.0
     # regenerate between steps, bracket every step by barrier + synchronize and sum the K bracketed times
     for s in range(a.steps):
@@ -202,9 +239,31 @@ def run_multi(a) -> dict:
         dist.barrier()
         elapsed += time.perf_counter() - t0
         assert info == 0, (s, info)
+        beat(f"step{s}")
     t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     stats = dd.dist_last_stats()
+    # one more step, untimed, with the library's HIP-event brackets on: every rank's own update-kernel time and the
+    # device time of its whole schedule, so that a scaling curve explains itself (update alone vs what the rank waited)
+    ch.set_profiling(True)
+    eng.generate(float(a.N), a.seed)
+    torch.cuda.synchronize()
+    dist.barrier()
+    info = factor()
+    torch.cuda.synchronize()
+    ch.set_profiling(False)
+    assert info == 0, info
+    st = ch.last_potrf_stats()
+    mine = torch.tensor([st["update_ms"], st["total_ms"], float(st["update_launches"]), st["update_flops"]], dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine)
+    stats["rank_update_ms"] = [round(float(x[0]), 3) for x in per_rank]
+    stats["rank_device_ms"] = [round(float(x[1]), 3) for x in per_rank]
+    stats["rank_update_launches"] = [int(x[2]) for x in per_rank]
+    stats["rank_update_tflops"] = [round(float(x[3]) / (float(x[0]) * 1e-3) / 1e12, 2) if float(x[0]) > 0 else None for x in per_rank]
+    stats["calibration"] = ch.calibration()
+    stats["counters"] = bool(lib_counters())
+    beat("profiled")
     # device time of each rank's own schedule in the last step (HIP events on its streams): max and min over ranks --
     # their spread is the block-cyclic imbalance plus what each rank waited for tiles
     dev = torch.tensor([ch.last_potrf_stats()["total_ms"]], dtype=torch.float64)
@@ -230,8 +289,114 @@ def run_multi(a) -> dict:
     return out
 
 
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this one (same
+    command line; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, and
+    supervise: a rank that exits non-zero, or --stall-timeout seconds without a heartbeat from any rank, ends the run --
+    the remaining ranks are killed (their process groups), ONE line with an "error" field is printed and the exit
+    status is non-zero.  This process never imports torch.cuda and never loads libcholmi.so: no GPU call, no exec."""
+    n = a.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    hb = tempfile.mkdtemp(prefix="cholmi_bench_hb_")
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "CHOLMI_BENCH_HB": hb})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True))
+
+    def pump(r, p):  # rank 0's stdout is the bench line; whatever the others print goes to stderr
+        for ln in p.stdout:
+            if r == 0:
+                lines.append(ln)
+            else:
+                sys.stderr.write(f"[rank {r}] {ln}")
+    threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+
+    def last_beat() -> float:
+        m = 0.0
+        for r in range(n):
+            try:
+                m = max(m, os.path.getmtime(os.path.join(hb, f"rank{r}")))
+            except OSError:
+                pass
+        return m
+
+    def where(r) -> str:
+        try:
+            return open(os.path.join(hb, f"rank{r}")).read().split()[0]
+        except (OSError, IndexError):
+            return "not started"
+
+    t_start = time.time()
+    error = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            error = {"error": f"rank {r} exited with status {c}", "failed_rank": r, "exit_status": c, "last_seen": where(r)}
+            break
+        if all(c == 0 for c in codes):
+            break
+        quiet = time.time() - max(last_beat(), t_start)
+        if quiet > a.stall_timeout:
+            alive = [r for r, c in enumerate(codes) if c is None]
+            error = {"error": f"no rank made progress for {quiet:.0f} s (limit {a.stall_timeout:.0f} s)", "failed_rank": None,
+                     "ranks_alive": alive, "last_seen": {str(r): where(r) for r in alive}}
+            break
+        time.sleep(0.2)
+    if error:
+        for p in procs:  # the survivors sit in a receive that will never complete: end them, whole process groups
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_kill = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+    for t in threads:
+        t.join(timeout=5)
+    for f in os.listdir(hb):
+        os.unlink(os.path.join(hb, f))
+    os.rmdir(hb)
+    if error:
+        line = {"metric": "fp64 TFLOP/s for NxN SPD Cholesky (N^3/3 flops / factorisation time)", "value": None,
+                "unit": "TFLOP/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup, "launcher": "self"}
+        line.update(error)
+        print(json.dumps(line), flush=True)
+        return 3
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            sys.stderr.write(f"[rank 0] {ln}")
+    if len(json_lines) != 1:
+        print(json.dumps({"error": f"rank 0 printed {len(json_lines)} JSON lines", "n_gpus": n, "value": None}), flush=True)
+        return 4
+    sys.stdout.write(json_lines[0])
+    sys.stdout.flush()
+    return 0
+
+
 def main() -> int:
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 or world > 1:
         r = run_multi(a)
@@ -285,6 +450,8 @@ def main() -> int:
                                                       "diag_step_us": [round(c[1], 1), round(c[3], 1)],
                                                       # False: chol_init's probe left the counter-linked chain off (events only)
                                                       "device_counters": r["counters"]}
+            # one extra step without the library's HIP-event brackets, beside the mean of the K bracketed ones
+            line["unprofiled_ms"] = round(r["unprofiled_ms"], 3)
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
             if a.cpu_extra_N and a.cpu_extra_N != a.cpu_N:
@@ -294,7 +461,18 @@ def main() -> int:
     if r.get("dist"):
         line["config"]["exchange"] = {"backend": r["backend"], "fallback": r.get("fallback"), "host_issue_us_per_wave": round(r["dist"]["issue_us_per_wave"], 1),
                                       "sends_per_rank0": r["dist"]["sends"], "bytes_sent_rank0": r["dist"]["bytes_sent"],
-                                      "rank_device_ms_last_step": [r["dist"]["device_ms_min"], r["dist"]["device_ms_max"]]}
+                                      "rank_device_ms_last_step": [r["dist"]["device_ms_min"], r["dist"]["device_ms_max"]],
+                                      # from one extra (untimed) step with the library's HIP-event brackets on, rank by rank:
+                                      # the update kernel's time (union of its launches), its rate, the rank's whole schedule
+                                      "rank_update_ms": r["dist"]["rank_update_ms"], "rank_update_tflops": r["dist"]["rank_update_tflops"],
+                                      "rank_update_launches": r["dist"]["rank_update_launches"],
+                                      "rank_device_ms_profiled_step": r["dist"]["rank_device_ms"]}
+        c = r["dist"]["calibration"]
+        line["config"]["schedule_calibration"] = {"mfma_probe_tflops": [round(c[0], 2), round(c[2], 2)],
+                                                  "diag_step_us": [round(c[1], 1), round(c[3], 1)],
+                                                  "device_counters": r["dist"]["counters"]}
+        if os.environ.get("CHOLMI_BENCH_HB"):
+            line["launcher"] = "self"
     print(json.dumps(line), flush=True)
     return 0
 

@@ -306,8 +306,27 @@ class ControlPlane:
                 raise RuntimeError("ExecuteBatch returned a status list of the wrong length")
         except Exception:  # a crashing batch: fall back to the one-task path with its retry rule
             for t in tasks:
-                if t.status == "pending" and not any(self._results[k].status == "completed" for k in t.expected_output_keys):
+                if t.status != "pending":
+                    continue
+                if all(self._results[k].status == "completed" for k in t.expected_output_keys):
+                    # its results were sent before the batch crashed (write-once: it cannot run again); book it as
+                    # the one-task path would have, so that flush() and on_task_done still see it
+                    t.attempts += 1
+                    t.status, t.output = "completed", ProcessStatus.Ok
+                    self.executed.append(t.task_id)
+                    if self.on_task_done:
+                        self.on_task_done(t)
+                elif not any(self._results[k].status == "completed" for k in t.expected_output_keys):
                     self._run(t)
+                else:  # some of its results exist, some do not: neither re-runnable nor complete
+                    t.attempts += 1
+                    t.status, t.output = "error", ProcessStatus("batch crashed after a partial send_result")
+                    for k in t.expected_output_keys:
+                        if self._results[k].status != "completed":
+                            self._results[k].status = "aborted"
+                    self.executed.append(t.task_id)
+                    if self.on_task_done:
+                        self.on_task_done(t)
             return
         for t, status in zip(tasks, statuses):
             t.attempts += 1

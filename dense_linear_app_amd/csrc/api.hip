@@ -50,7 +50,7 @@ struct Ctx {
   std::string last_error;
 };
 Ctx g;
-std::mutex g_mu;     // one ABI call at a time on the context
+std::recursive_mutex g_mu;     // one ABI call at a time on the context
 std::mutex g_err_mu; // chol_last_error's buffer
 
 void set_error(const char *msg) {
@@ -227,27 +227,51 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
   return r;
 }
 
-// ---- sub-matrix views over a user buffer: the library works on a compact image of the view's tiles
+// ---- sub-matrix views over a user buffer: the library works on a compact image of the view's tiles.
+// The user's matrix holds mb x mb tiles of bsiz elements (ld = mb); the image's tiles are mbi x mbi (mbi = mb
+// rounded up to 128, identity outside mb x mb): equal strides copy a whole tile column at once, a padded image
+// tile by tile with the two leading dimensions.
 int view_sync(chol_desc *d, bool in) {
-  const size_t tb = (size_t)d->bsizi * d->esize;
+  const size_t ti = (size_t)d->bsizi * d->esize, tu = (size_t)d->bsiz * d->esize;
   for (int J = 0; J < d->nt; ++J) {
-    char *user = reinterpret_cast<char *>(d->user_mat) + ((size_t)d->user_oi + (size_t)(J + d->user_oj) * d->user_lmt) * tb;
-    char *img = reinterpret_cast<char *>(d->mat) + (size_t)J * d->lmt * tb;
-    HIPCHECK(hipMemcpy(in ? img : user, in ? user : img, (size_t)d->mt * tb, hipMemcpyDefault));
+    char *user = reinterpret_cast<char *>(d->user_mat) + ((size_t)d->user_oi + (size_t)(J + d->user_oj) * d->user_lmt) * tu;
+    char *img = reinterpret_cast<char *>(d->mat) + (size_t)J * d->lmt * ti;
+    if (d->mbi == d->mb) {
+      HIPCHECK(hipMemcpy(in ? img : user, in ? user : img, (size_t)d->mt * ti, hipMemcpyDefault));
+      continue;
+    }
+    for (int I = 0; I < d->mt; ++I) {
+      char *u = user + (size_t)I * tu, *m = img + (size_t)I * ti;
+      const size_t ldu = (size_t)d->mb * d->esize, ldi = (size_t)d->mbi * d->esize;
+      HIPCHECK(hipMemcpy2D(in ? m : u, in ? ldi : ldu, in ? u : m, in ? ldu : ldi, ldu, d->nb, hipMemcpyDefault));
+    }
   }
   return 0;
 }
-struct ViewSync {
+// One entry point's body between the refresh of its views' images and their write-back, all under the context
+// lock (recursive: the bodies take it again); a failed refresh returns before the body runs, a failed write-back
+// is reported unless the body already failed.  The write-back also follows a body that returned info > 0
+// (a partly factored matrix, as LAPACK leaves it).
+struct ViewArg {
   chol_desc *d;
-  bool out;
-  int rc = 0;
-  ViewSync(chol_desc *dd, bool write_back) : d(dd && dd->user_mat ? dd : nullptr), out(write_back) {
-    if (d) rc = view_sync(d, true);
-  }
-  ~ViewSync() {
-    if (d && out && rc == 0) (void)view_sync(d, false);
-  }
+  bool write_back;
 };
+template <typename F>
+static int with_views(std::initializer_list<ViewArg> views, F &&body) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  for (const ViewArg &v : views)
+    if (v.d && v.d->user_mat) {
+      const int rc = view_sync(v.d, true);
+      if (rc) return rc;
+    }
+  int rc = body();
+  for (const ViewArg &v : views)
+    if (v.d && v.d->user_mat && v.write_back) {
+      const int r2 = view_sync(v.d, false);
+      if (r2 && rc >= 0) rc = r2;
+    }
+  return rc;
+}
 
 int build_worklist(chol_desc *d) {
   if (d->mt != d->nt) return 0;  // only square tile grids are factored
@@ -619,7 +643,7 @@ const char *chol_last_error(void) {
 }
 
 int chol_set_device(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (g.inited && device != g.r.device) return fail(-1, "chol_set_device after chol_init");
   g.r.device = device;
   return 0;
@@ -634,7 +658,7 @@ int chol_set_rank(int rank, int nranks) {
 
 int chol_init(int ncpu, int ngpu) {
   (void)ncpu;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (g.inited) return 0;
   if (ngpu < 1)
     return fail(CHOL_ERR_NO_GPU, "chol_init: ngpu must be >= 1 (this library has no CPU backend)");
@@ -684,7 +708,7 @@ int chol_init(int ncpu, int ngpu) {
 }
 
 int chol_finalize(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (!g.inited) return 0;
   (void)hipDeviceSynchronize();
   chol_internal_dist_finalize();
@@ -748,7 +772,7 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
     if (p * q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views of distributed matrices are not supported");
     if (mat) {
       // over a user buffer (v3's --mat user with offsets): the user's matrix is lm x ln in whole mb x nb tiles; the
-      // library keeps a compact image of the view's tiles and mirrors it around every operation (ViewSync)
+      // library keeps a compact image of the view's tiles and mirrors it around every operation (with_views)
       if (lm % mb || ln % nb || m % mb || n % nb || mb != nb)
         return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: a view over a user buffer needs whole square tiles (lm, ln, m, n multiples of mb = nb)");
       view_user = mat;
@@ -869,7 +893,7 @@ int chol_desc_set_version(chol_desc_t *d, unsigned long long version) {
 
 int chol_sync(void) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "chol_sync before chol_init");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
 }
@@ -958,7 +982,7 @@ int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *co
   if (n < 0 || n > BINFO_SLOTS / 2) return fail(-3, "potrf_batch: n");
   if (n == 0) return 0;
   if (!a_in || !a_out || !slots) return fail(-4, "potrf_batch: NULL pointer list");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const int rc = dtype == CHOL_REAL_DOUBLE ? potrf_batch_impl<double>(dtype, mb, n, a_in, a_out, versions, slots)
                                            : potrf_batch_impl<float>(dtype, mb, n, a_in, a_out, versions, slots);
   if (rc) return rc;
@@ -969,7 +993,7 @@ int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *co
 int chol_batch_info(int slot, int *info) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "batch_info before chol_init");
   if (!info || slot < 0 || slot >= BINFO_SLOTS || !g.d_binfo) return fail(-1, "batch_info: slot");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   HIPCHECK(hipMemcpy(info, g.d_binfo + slot, sizeof(int), hipMemcpyDeviceToHost));
   return 0;
@@ -984,7 +1008,7 @@ int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, c
   if (n < 0) return fail(-4, "tile_batch: n");
   if (n == 0) return 0;
   if (!c_in || !a || !c_out || (op == CHOL_BATCH_GEMM && !b)) return fail(-5, "tile_batch: NULL pointer list");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, dtype, mb, n, c_in, a, b, c_out, a_versions)
                                            : tile_batch_impl<float>(op, dtype, mb, n, c_in, a, b, c_out, a_versions);
   if (rc) return rc;
@@ -994,11 +1018,11 @@ int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, c
 
 // ---------------------------------------------------------------- POTRF
 int chol_potrf_tile(int uplo, chol_desc_t *A) {
-  ViewSync vsA(A, true);
+  return with_views({{A, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrf_tile: uplo");
   if (!A) return fail(-2, "potrf_tile: NULL descriptor");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (uplo == CHOL_LOWER)
     return A->dtype == CHOL_REAL_DOUBLE ? potrf_impl<double>(A) : potrf_impl<float>(A);
   // ChamUpper: A = U^T U with U = L^T.  Transpose the stored matrix in place (its upper
@@ -1020,11 +1044,12 @@ int chol_potrf_tile(int uplo, chol_desc_t *A) {
   flip();
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return rc;
+  });
 }
 
 int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_desc_t *A,
                    chol_desc_t *B) {
-  ViewSync vsA(A, false), vsB(B, true);
+  return with_views({{A, false}, {B, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "trsm_tile before chol_init");
   if (side != CHOL_LEFT && side != CHOL_RIGHT) return fail(-1, "trsm_tile: side");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-2, "trsm_tile: uplo");
@@ -1036,13 +1061,14 @@ int chol_trsm_tile(int side, int uplo, int trans, int diag, double alpha, chol_d
     return fail(CHOL_ERR_NOT_SUPPORTED, "trsm_tile: only (Right, Lower, Trans, NonUnit)");
   if (!single_tile_square(A) || !single_tile_square(B) || A->mb != B->mb || A->dtype != B->dtype)
     return fail(CHOL_ERR_NOT_SUPPORTED, "trsm_tile: needs two 1-tile descriptors of equal size and type");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   return A->dtype == CHOL_REAL_DOUBLE ? trsm_impl<double>(alpha, A, B) : trsm_impl<float>(alpha, A, B);
+  });
 }
 
 // ---------------------------------------------------------------- SYRK / GEMM
 int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *C) {
-  ViewSync vsA(A, false), vsC(C, true);
+  return with_views({{A, false}, {C, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "syrk_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "syrk_tile: uplo");
   if (trans != CHOL_NOTRANS && trans != CHOL_TRANS) return fail(-2, "syrk_tile: trans");
@@ -1052,14 +1078,15 @@ int chol_syrk_tile(int uplo, int trans, double alpha, chol_desc_t *A, double bet
     return fail(CHOL_ERR_NOT_SUPPORTED, "syrk_tile: only (Lower, NoTrans)");
   if (!single_tile_square(A) || !single_tile_square(C) || A->mb != C->mb || A->dtype != C->dtype)
     return fail(CHOL_ERR_NOT_SUPPORTED, "syrk_tile: needs two 1-tile descriptors of equal size and type");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   return A->dtype == CHOL_REAL_DOUBLE ? gemm_impl<double>(alpha, A, A, beta, C, true)
                                       : gemm_impl<float>(alpha, A, A, beta, C, true);
+  });
 }
 
 int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_desc_t *B,
                    double beta, chol_desc_t *C) {
-  ViewSync vsA(A, false), vsB(B, false), vsC(C, true);
+  return with_views({{A, false}, {B, false}, {C, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "gemm_tile before chol_init");
   if (transA != CHOL_NOTRANS && transA != CHOL_TRANS) return fail(-1, "gemm_tile: transA");
   if (transB != CHOL_NOTRANS && transB != CHOL_TRANS) return fail(-2, "gemm_tile: transB");
@@ -1071,14 +1098,15 @@ int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_de
   if (!single_tile_square(A) || !single_tile_square(B) || !single_tile_square(C) || A->mb != C->mb ||
       B->mb != C->mb || A->dtype != C->dtype || B->dtype != C->dtype)
     return fail(CHOL_ERR_NOT_SUPPORTED, "gemm_tile: needs three 1-tile descriptors of equal size and type");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   return A->dtype == CHOL_REAL_DOUBLE ? gemm_impl<double>(alpha, A, B, beta, C, false)
                                       : gemm_impl<float>(alpha, A, B, beta, C, false);
+  });
 }
 
 // ---------------------------------------------------------------- generator / layout / residual
 int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long seed) {
-  ViewSync vsA(A, true);
+  return with_views({{A, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "plgsy_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-2, "plgsy_tile: uplo");
   const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
@@ -1086,7 +1114,7 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
   if (!A->on_device) return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: descriptor must be device-resident");
   if (A->mt == 1 && A->nt == 1 && (A->m != A->mb || A->n != A->nb) && !A->padded)
     return fail(CHOL_ERR_NOT_SUPPORTED, "plgsy_tile: partial single tile");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const LocalMat L = local_mat(A, A->mat);
   if (A->dtype == CHOL_REAL_DOUBLE)
     launch_plgsy<double>(g.r.st[ST_MAIN], L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
@@ -1094,6 +1122,7 @@ int chol_plgsy_tile(double bump, int uplo, chol_desc_t *A, unsigned long long se
     launch_plgsy<float>(g.r.st[ST_MAIN], L, A->lnt, A->prow, A->pcol, bump, seed, A->mb, (long)A->lm, side);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
+  });
 }
 
 // ---------------------------------------------------------------- V6 validation block
@@ -1124,7 +1153,7 @@ static TileGeo geo_of(const chol_desc *d) {
 }
 
 int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
-  ViewSync vsA(A, false), vsB(B, true);
+  return with_views({{A, false}, {B, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lacpy_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER && uplo != CHOL_UPPER_LOWER) return fail(-1, "lacpy_tile: uplo");
   int rc = resident_whole("lacpy_tile", A);
@@ -1132,7 +1161,7 @@ int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
   rc = resident_whole("lacpy_tile", B);
   if (rc) return rc;
   if (!same_geometry(A, B)) return fail(-3, "lacpy_tile: descriptors differ in shape, tiling or type");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const int side = uplo == CHOL_LOWER ? 1 : uplo == CHOL_UPPER ? 2 : 0;
   if (A->dtype == CHOL_REAL_DOUBLE)
     launch_lacpy<double>(g.r.st[ST_MAIN], geo_of(A), side, (const double *)A->mat, (double *)B->mat);
@@ -1140,10 +1169,11 @@ int chol_lacpy_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
     launch_lacpy<float>(g.r.st[ST_MAIN], geo_of(A), side, (const float *)A->mat, (float *)B->mat);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
+  });
 }
 
 int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_desc_t *B) {
-  ViewSync vsA(A, false), vsB(B, true);
+  return with_views({{A, false}, {B, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "geadd_tile before chol_init");
   if (trans != CHOL_NOTRANS) return fail(CHOL_ERR_NOT_SUPPORTED, "geadd_tile: only ChamNoTrans (V6:83)");
   int rc = resident_whole("geadd_tile", A);
@@ -1151,17 +1181,18 @@ int chol_geadd_tile(int trans, double alpha, chol_desc_t *A, double beta, chol_d
   rc = resident_whole("geadd_tile", B);
   if (rc) return rc;
   if (!same_geometry(A, B)) return fail(-5, "geadd_tile: descriptors differ in shape, tiling or type");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (A->dtype == CHOL_REAL_DOUBLE)
     launch_geadd<double>(g.r.st[ST_MAIN], geo_of(A), alpha, (const double *)A->mat, beta, (double *)B->mat);
   else
     launch_geadd<float>(g.r.st[ST_MAIN], geo_of(A), alpha, (const float *)A->mat, beta, (float *)B->mat);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   return 0;
+  });
 }
 
 int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
-  ViewSync vsA(A, false);
+  return with_views({{A, false}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lange_tile before chol_init");
   if (!value) return fail(-3, "lange_tile: NULL value");
   int kind;
@@ -1174,7 +1205,7 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
   }
   int rc = resident_whole("lange_tile", A);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const TileGeo ge = geo_of(A);
   int rcw = ensure_work((size_t)(std::max(ge.m, ge.n) + 2) * sizeof(double));
   if (rcw) return rcw;
@@ -1189,17 +1220,18 @@ int chol_lange_tile(int norm, chol_desc_t *A, double *value) {
   if (e != hipSuccess) return fail_hip(e, "lange_tile", __LINE__);
   *value = kind == 3 ? std::sqrt(v) : v;
   return 0;
+  });
 }
 
 int chol_lauum_tile(int uplo, chol_desc_t *A) {
-  ViewSync vsA(A, true);
+  return with_views({{A, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "lauum_tile before chol_init");
   if (uplo != CHOL_LOWER) return fail(CHOL_ERR_NOT_SUPPORTED, "lauum_tile: only ChamLower (V6:80)");
   int rc = resident_whole("lauum_tile", A);
   if (rc) return rc;
   if (A->mt != A->nt || A->lm != A->ln) return fail(-2, "lauum_tile: matrix is not square");
   if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "lauum_tile: stored tile edge must be a multiple of 64");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const size_t bytes = (size_t)A->mt * A->nt * A->bsizi * A->esize;
   void *tmp = nullptr;
   if (hipMalloc(&tmp, bytes) != hipSuccess) {
@@ -1222,11 +1254,12 @@ int chol_lauum_tile(int uplo, chol_desc_t *A) {
   (void)hipFree(tmp);
   if (e != hipSuccess) return fail_hip(e, "lauum_tile", __LINE__);
   return 0;
+  });
 }
 
 // ---------------------------------------------------------------- solve with the factor
 int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
-  ViewSync vsA(A, false), vsB(B, true);
+  return with_views({{A, false}, {B, true}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrs_tile before chol_init");
   if (uplo != CHOL_LOWER && uplo != CHOL_UPPER) return fail(-1, "potrs_tile: uplo");
   int rc = resident_whole("potrs_tile", A);
@@ -1238,7 +1271,7 @@ int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
     return fail(-3, "potrs_tile: B must have A's order, tile size and type");
   if (A->mbi % 64) return fail(CHOL_ERR_NOT_SUPPORTED, "potrs_tile: stored tile edge must be a multiple of 64");
   CHECK_WINV(A, "potrs_tile");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   // ChamUpper: A = U^T U with U = L^T -- transpose the factor's storage in place around the Lower solve
   // (as chol_potrf_tile does around the Lower factorisation); the strict lower triangle comes back as it was
   auto flip = [&]() {
@@ -1254,6 +1287,7 @@ int chol_potrs_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
     HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
   }
   return rc;
+  });
 }
 
 int chol_posv_tile(int uplo, chol_desc_t *A, chol_desc_t *B) {
@@ -1268,7 +1302,7 @@ static inline int tile_rows(const chol_desc *d, int I) { return std::min(d->mb, 
 static inline int tile_cols(const chol_desc *d, int J) { return std::min(d->nb, d->ln - J * d->nb); }
 
 int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
-  ViewSync vs(d, true);
+  return with_views({{d, true}}, [&]() -> int {
   if (!d || !host_tile) return fail(-1, "tile_upload: NULL");
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_upload: tile not owned by this process");
@@ -1278,10 +1312,11 @@ int chol_tile_upload(chol_desc_t *d, int I, int J, const void *host_tile) {
   HIPCHECK(hipMemcpy2D(dst, (size_t)d->mbi * d->esize, host_tile, (size_t)d->mb * d->esize,
                        (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
   return 0;
+  });
 }
 
 int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
-  ViewSync vs(d, false);
+  return with_views({{d, false}}, [&]() -> int {
   if (!d || !host_tile) return fail(-1, "tile_download: NULL");
   if (I < 0 || I >= d->mt || J < 0 || J >= d->nt || I % d->p != d->prow || J % d->q != d->pcol)
     return fail(-2, "tile_download: tile not owned by this process");
@@ -1291,10 +1326,11 @@ int chol_tile_download(chol_desc_t *d, int I, int J, void *host_tile) {
   HIPCHECK(hipMemcpy2D(host_tile, (size_t)d->mb * d->esize, src, (size_t)d->mbi * d->esize,
                        (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
   return 0;
+  });
 }
 
 int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
-  ViewSync vs(d, true);
+  return with_views({{d, true}}, [&]() -> int {
   if (!A || !d) return fail(-1, "lapack_to_tile: NULL");
   if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "lapack_to_tile: single-process descriptors only");
   if (lda < d->lm) return fail(-2, "lapack_to_tile: lda");
@@ -1306,10 +1342,11 @@ int chol_lapack_to_tile(const void *A, int lda, chol_desc_t *d) {
                            (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
     }
   return 0;
+  });
 }
 
 int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
-  ViewSync vs(d, false);
+  return with_views({{d, false}}, [&]() -> int {
   if (!A || !d) return fail(-1, "tile_to_lapack: NULL");
   if (d->p * d->q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_to_lapack: single-process descriptors only");
   if (lda < d->lm) return fail(-3, "tile_to_lapack: lda");
@@ -1321,16 +1358,17 @@ int chol_tile_to_lapack(chol_desc_t *d, void *A, int lda) {
                            (size_t)tile_rows(d, I) * d->esize, tile_cols(d, J), hipMemcpyDefault));
     }
   return 0;
+  });
 }
 
 static int residual_common(chol_desc_t *L, double bump, unsigned long long seed, double *rel_fro,
                            double *rel_inf) {
-  ViewSync vsL(L, false);
+  return with_views({{L, false}}, [&]() -> int {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "residual before chol_init");
   if (!L || (!rel_fro && !rel_inf)) return fail(-1, "residual: NULL");
   if (L->p * L->q != 1 || !L->on_device || L->mt != L->nt || L->mb != L->nb || L->mbi % MACRO)
     return fail(CHOL_ERR_NOT_SUPPORTED, "residual: single-process device-resident square tiled matrix only");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   const long n = L->lm;
   double *rows = nullptr;
   if (rel_inf) {
@@ -1361,6 +1399,7 @@ static int residual_common(chol_desc_t *L, double bump, unsigned long long seed,
     *rel_inf = rmax / (amax > 0 ? amax : 1.0);  // V6:84
   }
   return 0;
+  });
 }
 
 int chol_residual_plgsy(chol_desc_t *L, double bump, unsigned long long seed, double *rel) {
@@ -1393,7 +1432,7 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   if (ablate != 0)
     return fail(CHOL_ERR_NOT_SUPPORTED, "bench_update: the ablation twin of the update is a diagnostic build (make DIAG=1)");
 #endif
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int rc = ensure_events(2);
   if (rc) return rc;
   PanelRef pan;
@@ -1448,7 +1487,7 @@ int chol_debug_stamps(int enable, unsigned long long *out, int max_pairs) {
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "mfma_probe before chol_init");
   if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(-2, "mfma_probe: arguments");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   return mfma_probe_on(&g.r, dtype, waves_per_simd, 4000, tflops);
 }
 

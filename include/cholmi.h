@@ -212,8 +212,11 @@ void chol_extract_block(const double *A, int N, int LDA, int B, int bi, int bj, 
  * chol_potrf_tile: total ms and the trailing-update kernel's launch count / ms. */
 int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launches,
                           double *update_flops);
-/* 1 = record per-launch HIP events around the trailing-update kernel (serialises
- * the streams; for bench.py's roofline leg only), 0 = off (default). */
+/* 1 = bracket the trailing-update launches of every wave (pair of waves) with HIP events
+ * on the stream the big launch runs on; the wait that closes a bracket joins launches the
+ * next wave's big launch depends on anyway, so no dependency is added (walker.h) -- what
+ * remains is the cost of the event records, which bench.py puts on record beside the
+ * bracketed steps ("unprofiled_ms").  For bench.py's roofline leg; 0 = off (default). */
 int chol_set_profiling(int on);
 
 /* Diagnostic: time the trailing-update launch of wave k alone (best of `reps`), on whatever

@@ -411,15 +411,17 @@ def test_tile_batches_through_the_raw_abi(cham, dtype):
     assert L.chol_tile_batch(3, cdt, 100, n, ptrs(dC), ptrs(dA), ptrs(dB), ptrs(outs), None, 0) == -104
 
 
+@pytest.mark.parametrize("mb", [256, 192])
 @pytest.mark.parametrize("where", ["host", "device"])
-def test_sub_matrix_view_over_a_user_buffer(cham, orc, where):
+def test_sub_matrix_view_over_a_user_buffer(cham, orc, where, mb):
     """CHAMELEON_Desc_Create(mat != NULL, ..., i, j, m, n): a tile-aligned view of the user's tile matrix (v3 driver:
     --mat user with offsets).  The library mirrors the view through a device image: the view's tiles are factored in
-    the user's buffer, every other tile of it stays bit for bit what it was."""
+    the user's buffer, every other tile of it stays bit for bit what it was.  mb = 192 (the reference's NB sweep): the
+    image's tiles are padded to 256, the user's are not -- the two sides are addressed with their own tile strides."""
     import torch
 
     ch = cham
-    mb, lt, oi, oj, vt = 256, 5, 1, 2, 3  # user matrix: 5 x 5 tiles; view: 3 x 3 tiles starting at tile (1, 2)
+    lt, oi, oj, vt = 5, 1, 2, 3  # user matrix: 5 x 5 tiles; view: 3 x 3 tiles starting at tile (1, 2)
     lm = lt * mb
     m = vt * mb
     rng = np.random.default_rng(9)

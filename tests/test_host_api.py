@@ -166,6 +166,31 @@ def test_results_are_write_once():
         rc.upload_result_data(sid, rid, b"def")
 
 
+def test_a_crashing_batch_keeps_the_books_of_tasks_that_had_already_sent_their_results():
+    """ControlPlane._run_batch's fallback: ExecuteBatch raises after its first task has sent its result.  That task is
+    write-once done -- it must still reach `executed`, `completed` and on_task_done; the others run one by one."""
+    class Crashy(DagCholeskyWorker):
+        def ExecuteBatch(self, handlers):
+            self.Execute(handlers[0])
+            raise RuntimeError("boom")
+
+    plane = ak.ControlPlane(batch_ready=True)
+    plane.register_worker(client.PARTITION, Crashy(backend=OracleTileBackend()))
+    sid = ak.SessionsClient(plane).create_session(client.default_task_options(), [client.PARTITION])
+    seen = []
+    plane.on_task_done = lambda t: seen.append(t.task_id)
+    rc, tc = ak.ResultsClient(plane), ak.TasksClient(plane)
+    ids = rc.create_results_metadata(sid, ["o1", "o2", "p1", "p2", "a"])
+    rc.upload_result_data(sid, ids["a"], (4 * np.eye(4)).tobytes())
+    for k in ("p1", "p2"):
+        rc.upload_result_data(sid, ids[k], '{"op":"POTRF","B":4,"in":"%s"}' % ids["a"])
+    tids = tc.submit_tasks(sid, [ak.TaskCreation(ids["p1"], [ids["o1"]], [ids["a"]]),
+                                 ak.TaskCreation(ids["p2"], [ids["o2"]], [ids["a"]])], client.default_task_options())
+    ak.EventsClient(plane).wait_for_result_availability(sid, [ids["o1"], ids["o2"]])
+    assert sorted(seen) == sorted(tids) and sorted(plane.executed) == sorted(tids)
+    assert all(tc.get_task_output(t) == ak.ProcessStatus.Ok for t in tids)
+
+
 def test_client_dag_default_case_matches_golden():
     """C1/C2 default N=12, B=4: 3 waves, 3/3/3/1 tasks; factor equals the committed fixture."""
     res = client.run_cholesky_dag(12, 4, worker=DagCholeskyWorker(backend=OracleTileBackend()))
