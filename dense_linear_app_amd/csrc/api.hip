@@ -559,6 +559,53 @@ int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from) {
   // the two communication streams of a p x q factorisation (walker.h); idle otherwise
   HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_CX], hipStreamNonBlocking, hi));
   HIPCHECK(hipStreamCreateWithPriority(&r->st[ST_PX], hipStreamNonBlocking, hi));
+  {
+    // The panel chain's streams must not share a dispatch pipe with a stream that carries trailing-update launches
+    // (ST_MAIN; ST_U1): such a launch, longer than one round of workgroups, holds back every kernel of a stream behind
+    // the same pipe until its last workgroup is placed (kernels.hip: k_pipe_big).  Probe the pairs; replace a victim
+    // by a fresh stream (the old one is kept, so that its queue is not handed out again) and probe again.
+    const char *e = getenv("CHOLMI_PIPE_PROBE");
+    if (!e || atoi(e) != 0) {
+      hipDeviceProp_t prop;
+      HIPCHECK(hipGetDeviceProperties(&prop, device));
+      unsigned long long *t = nullptr;
+      HIPCHECK(hipMalloc(&t, 64));
+      auto blocked = [&](int big, int small, bool *out) -> int {
+        HIPCHECK(hipMemset(t, 0, 64));
+        cholmi::launch_pipe_probe(r->st[big], r->st[small], t, prop.multiProcessorCount);
+        HIPCHECK(hipStreamSynchronize(r->st[big]));
+        HIPCHECK(hipStreamSynchronize(r->st[small]));
+        unsigned long long h[2];
+        HIPCHECK(hipMemcpy(h, t, sizeof h, hipMemcpyDeviceToHost));
+        *out = h[1] > h[0] + 3000;  // started more than 30 us behind the big launch's first workgroup: it waited for rounds
+        return 0;
+      };
+      const int victims[4] = {ST_PANEL, ST_TRSM, ST_CX, ST_U1};
+      const int mid = lo - 1 > hi ? lo - 1 : hi;
+      const int prio_of[ST_COUNT] = {lo, hi, hi, mid, hi, hi};
+      for (int vi = 0; vi < 4; ++vi) {
+        const int v = victims[vi];
+        for (int attempt = 0;; ++attempt) {
+          bool b1 = false, b2 = false;
+          int rc = blocked(ST_MAIN, v, &b1);
+          if (rc) return rc;
+          if (v != ST_U1) rc = blocked(ST_U1, v, &b2);
+          if (rc) return rc;
+          if (!b1 && !b2) break;
+          if (attempt == 6) {
+            ++r->stream_collisions;
+            break;
+          }
+          r->retired.push_back(r->st[v]);
+          HIPCHECK(hipStreamCreateWithPriority(&r->st[v], hipStreamNonBlocking, prio_of[v]));
+          ++r->stream_swaps;
+        }
+      }
+      (void)hipFree(t);
+      if (getenv("CHOLMI_VERBOSE"))
+        fprintf(stderr, "[cholmi] stream pipe probe: %d stream(s) replaced, %d pair(s) still colliding\n", r->stream_swaps, r->stream_collisions);
+    }
+  }
   r->winv_bytes = (size_t)32 * MACRO * MACRO * sizeof(double);  // tiles up to 4096
   HIPCHECK(hipMalloc(&r->winv, 2 * r->winv_bytes));  // two sets: the walker alternates them by wave parity
   HIPCHECK(hipMalloc(&r->d_info, sizeof(int)));
@@ -587,6 +634,19 @@ int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from) {
         (void)hipFree(r->d_sem);
         r->d_sem = nullptr;
       } else {
+        // the flow form of the tile POTRF runs its row-slab kernel on ST_CX (idle on one GPU; on a grid it carries
+        // the small messages, which follow the POTRF anyway): that stream and ST_PANEL must not share a queue either
+        r->flow_ok = true;
+        const hipStream_t fpairs[2][2] = {{r->st[ST_CX], r->st[ST_PANEL]}, {r->st[ST_PANEL], r->st[ST_CX]}};
+        for (int t = 0; t < 2 && r->flow_ok; ++t) {
+          int *sem = r->d_sem + 64 * (4 + t), *res = r->d_sem + 64 * (4 + t) + 32;
+          cholmi::launch_sem_probe(fpairs[t][0], fpairs[t][1], sem, res);
+          HIPCHECK(hipStreamSynchronize(fpairs[t][0]));
+          HIPCHECK(hipStreamSynchronize(fpairs[t][1]));
+          int v = 0;
+          HIPCHECK(hipMemcpy(&v, res, sizeof(int), hipMemcpyDeviceToHost));
+          r->flow_ok = (v == 1);
+        }
         HIPCHECK(hipMemset(r->d_sem, 0, 1024 * sizeof(int)));
       }
     }
@@ -613,6 +673,8 @@ int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from) {
 void rank_ctx_destroy(RankCtx *r) {
   for (auto e : r->events) (void)hipEventDestroy(e);
   r->events.clear();
+  if (r->ev_flow) (void)hipEventDestroy(r->ev_flow);
+  r->ev_flow = nullptr;
   r->pool.free_all();
   if (r->winv) (void)hipFree(r->winv);
   if (r->d_info) (void)hipFree(r->d_info);
@@ -624,6 +686,8 @@ void rank_ctx_destroy(RankCtx *r) {
     if (r->st[i]) (void)hipStreamDestroy(r->st[i]);
     r->st[i] = nullptr;
   }
+  for (hipStream_t s : r->retired) (void)hipStreamDestroy(s);
+  r->retired.clear();
 }
 
 }  // namespace cholmi
@@ -686,6 +750,10 @@ int chol_init(int ncpu, int ngpu) {
     cholmi::g_poll_max_wgs = room < 0 ? 0 : (room < 48 ? room : 48);
   }
   if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
+  if (const char *e = getenv("CHOLMI_FLOW")) cholmi::g_flow = atoi(e);
+  if (const char *e = getenv("CHOLMI_FLOW_MAX_NBM")) cholmi::g_flow_max_nbm = std::min(8, atoi(e));
+  if (const char *e = getenv("CHOLMI_FLOW_MIN_NBM")) cholmi::g_flow_min_nbm = std::max(2, atoi(e));
+  if (const char *e = getenv("CHOLMI_FLOW_FENCES")) cholmi::g_flow_fences = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED_MAX")) cholmi::g_intile_fused_max = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
@@ -1511,6 +1579,8 @@ int chol_debug_update_kernel(int dtype, char *buf, int buflen) {
 // What the walker's regime switches are measured in, as taken at chol_init (or from CHOLMI_CALIB):
 // out[0..3] = fp64 MFMA probe [TFLOP/s], fp64 diagonal-block step [us], fp32 probe, fp32 step;
 // out[4..7] = the derived per-dtype update rate [TFLOP/s] and panel step [us] the walker uses (walker.h: WaveCalib)
+int chol_debug_flow_waves(void) { return g.r.flow_waves; }
+
 int chol_debug_calibration(double *out8) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "debug_calibration before chol_init");
   if (!out8) return fail(-1, "debug_calibration: NULL");

@@ -44,7 +44,7 @@ namespace cholmi {
 // streams of one rank's factorisation (walker.h)
 enum { ST_MAIN = 0, ST_PANEL, ST_TRSM, ST_U1, ST_CX, ST_PX, ST_COUNT };
 
-constexpr int SEM_SLOTS = 16384;   // device-side counters: 3 mb/128 + 1 per tile column ...
+constexpr int SEM_SLOTS = 65536;   // device-side counters: 3 mb/128 + 1 per tile column (+ the flow's control block) ...
 constexpr int TILE_SEM_SETS = 8;   // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
 constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
 
@@ -72,12 +72,18 @@ struct RankCtx {
   size_t winv_bytes = 0;
   int *d_info = nullptr;
   int *d_sem = nullptr;  // device-side dependency counters of the panel chain (kernels.hip: sem_wait), or null
+  bool flow_ok = false;  // ... and ST_CX / ST_PANEL have queues of their own: the flow form of the tile POTRF may be used
   unsigned tile_sem_next = 0;
   std::vector<hipEvent_t> events;
+  std::vector<hipStream_t> retired;  // streams chol_init replaced because an update stream's launches held theirs back
+  int stream_swaps = 0;          // ... how many, and pairs that still collide after the attempts
+  int stream_collisions = 0;
+  hipEvent_t ev_flow = nullptr;  // joins ST_CX to ST_PANEL once, at the first flow-form wave of a factorisation
   bool profiling = false;
   // stats of the last whole-matrix potrf
   double total_ms = 0, update_ms = 0, update_flops = 0, issue_us = 0;
   int update_launches = 0;
+  int flow_waves = 0;  // waves of the last whole-matrix potrf whose tile POTRF ran in flow form (kernels.hip: k_flow_factor)
   long long sends = 0, recvs = 0, bytes_sent = 0;
   DevPool pool;
   // measured once at creation, by dtype (0 = f64, 1 = f32): the register-only MFMA stream's rate [TFLOP/s]
@@ -122,6 +128,12 @@ extern int g_variant;
 extern int g_intile_small;
 extern int g_trsm_small_max;
 extern int g_poll_max_wgs;
+// the flow form of a counter-linked wave's tile POTRF (kernels.hip: k_flow_factor): does it apply to tiles of nbm 128-blocks
+bool flow_applies(int nbm);
+extern int g_flow;
+extern int g_flow_min_nbm;
+extern int g_flow_max_nbm;
+extern int g_flow_fences;
 extern int g_intile_fused;
 extern int g_intile_fused_max;
 extern int g_min_units;
@@ -159,6 +171,9 @@ void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 // chol_init's probe: the consumer kernel goes first, polls *sem (zeroed) for <= ~20 ms and writes 1 (seen) or
 // 2 (gave up) to *result; the producer kernel raises *sem
 void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result);
+// chol_init's probe of two streams' dispatch paths (kernels.hip: k_pipe_big): t[0] / t[1] = start of the many-round launch on
+// `big` / of the one-wave kernel launched right behind it on `small` (100 MHz ticks)
+void launch_pipe_probe(hipStream_t big, hipStream_t small, unsigned long long *t, int cus);
 
 // The chain-bound form of a wave (device-side edges, kernels.hip: sem_wait).  The SYRK on the next diagonal
 // tile, C(k+1,k+1) -= L(k+1,k) L(k+1,k)^T, is cut into the K = 128 slices of the head tile's block columns
@@ -171,7 +186,14 @@ struct SyrkPipe {
   hipStream_t su;  // has already waited for the earlier writers of that tile
   int *sem;        // 3 nbm + 1 zeroed counters of this wave, 32 ints (one 128-byte line) apart; the last one
                    // counts the last slice's workgroups: n (n + 1) / 2, n = mb / 64
+  // the tile POTRF as a flow (kernels.hip: k_flow_factor / k_flow_rows), or null: its zeroed control block
+  // (flow_lines(nbm, nbm) lines), the stream the row-slab waves run on, an event to join it once
+  int *fc = nullptr;
+  hipStream_t sflow = nullptr;
+  hipEvent_t ev_flow = nullptr;
+  bool join_flow = false;  // the wave before was not in flow form
 };
+inline int flow_ctl_lines(int nbm) { return nbm >= 2 && nbm <= 8 ? 1 + nbm + 2 * nbm * nbm : 0; }
 
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,

@@ -102,6 +102,11 @@ struct HipOps {
   void *winv(int par) { return (char *)r.winv + (size_t)par * r.winv_bytes; }
   void *alloc(size_t bytes) { return r.pool.get(bytes); }
   int *sem(int k, int which, int per_wave) { return r.d_sem + ((size_t)per_wave * k + which) * 32; }
+  bool flow_ok() const { return r.flow_ok; }
+  void *flow_event() {
+    if (!r.ev_flow) (void)hipEventCreateWithFlags(&r.ev_flow, hipEventDisableTiming);
+    return r.ev_flow;
+  }
   int launched() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
@@ -194,6 +199,8 @@ struct CbOps {
   void *winv(int) { return nullptr; }
   void *alloc(size_t bytes) { return cb.alloc(cb.ctx, bytes); }
   int *sem(int, int, int) { return nullptr; }
+  bool flow_ok() const { return false; }
+  void *flow_event() { return nullptr; }
   int begin(int, int, int) { return 0; }
   int rec(int, int) { return 0; }
   int wt(int, int) { return 0; }
@@ -472,13 +479,14 @@ int walk_t(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool re
     // leave nothing half-open behind a failure: close the transport groups, let kernels that poll a counter go
     // (every counter raised past any target), drain the streams
     if (cm) (void)cm->end(0), (void)cm->end(1);
-    if (ops.sem_ok) (void)hipMemsetD32Async((hipDeviceptr_t)r->d_sem, 0x3fffffff, (size_t)SEM_SLOTS * 32, r->st[ST_CX]);
+    if (ops.sem_ok) (void)hipMemsetD32Async((hipDeviceptr_t)r->d_sem, 0x3fffffff, (size_t)SEM_SLOTS * 32, r->st[ST_PX]);  // (ST_PX: no polling kernel ever runs on it)
     for (int s = 0; s < ST_COUNT; ++s) (void)hipStreamSynchronize(r->st[s]);
     (void)hipGetLastError();
   }
   r->pool.release_all();
   r->update_flops = w.upd_flops;
   r->update_launches = w.upd_launches;
+  r->flow_waves = w.flow_waves;
   r->issue_us = w.issue_us / (g.nt > 0 ? g.nt : 1);  // per wave
   r->sends = cm ? cm->nsend : 0, r->recvs = cm ? cm->nrecv : 0, r->bytes_sent = cm ? cm->bytes_sent : 0;
   if (rc) return rc;

@@ -236,6 +236,42 @@ __device__ __forceinline__ void sem_signal(int *sem) {
   }
 }
 
+// ------------------------------------------------------------------------------
+// Hand-offs inside one launch (k_flow_factor / k_flow_rows): the payload is stored write-through (sc1) and read
+// by sc1 loads (L1 bypassed, served by L2 / the fabric), the storing wave drains its stores (s_waitcnt vmcnt(0))
+// before it -- or, behind a workgroup barrier, one lane of its workgroup -- raises the counter, and the consumer
+// polls the counter with sc1 loads and loads only after its poll has matched (MI355X_MICROARCH.md, "Valid forms":
+// the form with neither a release nor an acquire fence; ~1 us per hop instead of ~3.5).  CHOLMI_FLOW_FENCES=1 adds
+// an agent-scope release before every counter add and an acquire after every poll (diagnostic).
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ double load_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_pair_sc1(double *p, double a, double b) {  // p 16-byte aligned
+  d2_t v = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_pair_sc1(float *p, float a, float b) {  // p 8-byte aligned
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  f2_t v = {a, b};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// diagnostic (chol_debug_stamps): one 8-word record {start, end, tag, step} of the calling workgroup
+__device__ __forceinline__ void dbg_mark(unsigned long long *dbg, int tag, int step, unsigned long long t0) {
+  if (dbg && threadIdx.x == 0) {
+    const unsigned long long slot = atomicAdd(dbg, 1ull);
+    if (slot < 1000) {
+      unsigned long long *p = dbg + 1 + 8 * slot;
+      p[0] = t0;
+      p[1] = __builtin_amdgcn_s_memrealtime();
+      p[2] = (unsigned long long)tag;
+      p[3] = (unsigned long long)step;
+    }
+  }
+}
+
 // chol_init's check (see above): the consumer is launched first and polls for at most ~20 ms
 __global__ void k_sem_probe_wait(const int *sem, int *result) {
   int ok = 2;
@@ -1794,10 +1830,20 @@ struct DiagLds {
   int failed;
 };
 
+// FLOW (k_flow_factor): the block is already in L.S (loaded, and updated by the earlier steps' products, by the
+// caller); every finished 16-column panel of the factor and the inverse of its 16 x 16 diagonal block are
+// PUBLISHED for the row-slab waves of k_flow_rows -- write-through (sc1) stores into the tile / winv right after
+// phase A, the panel counter raised one phase later, behind the barrier that has drained them -- so the factor
+// is not stored again at the end; a failed pivot raises the flow's abort word.
 template <typename T>
+struct FlowPub {
+  int *fpan;   // panels of this diagonal block published so far (0 .. 8)
+  int *abort;  // the flow's abort word
+};
+template <typename T, bool FLOW = false>
 __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ winv, int *info,
                                                 int info_base, int factor, DiagLds<T> &L,
-                                                unsigned long long *ph = nullptr) {
+                                                unsigned long long *ph = nullptr, const FlowPub<T> *fp = nullptr) {
   constexpr int n = MACRO, NB = 16, NP = DB_NP;
   unsigned long long tA = 0, tB = 0, tl = 0;
 #define PH_NOW() (ph ? __builtin_amdgcn_s_memrealtime() : 0ull)
@@ -1811,7 +1857,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   // (no per-element index arithmetic), 16 independent accesses in flight, rows of consecutive
   // threads contiguous in global memory.
   const int gi = t & (n - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
-  {
+  if constexpr (!FLOW) {
     // all four block columns of the row at once: up to 64 independent loads in flight per thread
     // (the kernel starts cold, behind the launch that produced the block: latency, not bandwidth)
     T v[4][16];
@@ -1831,11 +1877,13 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
     }
   }
-  if (t == 0) {
-    failed = 0;
-    L.colready = 0;
+  if constexpr (!FLOW) {
+    if (t == 0) {
+      failed = 0;
+      L.colready = 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (ph && t == 0) ph[0] = PH_NOW();  // loaded
 
   if (factor) {
@@ -2019,7 +2067,33 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       __syncthreads();
       if (failed) {
         if (failed != 1 && t == 0) atomicCAS(info, 0, 0x7fffffff);  // a consumer gave up waiting (ColFetch)
+        if constexpr (FLOW) {
+          if (t == 0) __hip_atomic_store(fp->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
+      }
+      if constexpr (FLOW) {
+        // publish panel p: rows 16 p .. 127 of its 16 columns, on or below the diagonal; one wave instruction
+        // stores one column (two consecutive rows per lane), so every 128-byte line is written whole by one store
+        const int row0 = 2 * (t & 63);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 4 * q + (t >> 6), jg = j0 + col;
+          if (row0 + 1 >= jg) {
+            const T *src = S + db_off(row0 >> 4, p) + (row0 & 15) + col * DB_LD;
+            const T v0 = src[0], v1 = src[1];
+            T *dst = A + row0 + (size_t)jg * ld;
+            if (row0 >= jg) store_pair_sc1(dst, v0, v1);
+            else store_sc1(dst + 1, v1);
+          }
+        }
+        // ... and the inverse of its 16 x 16 diagonal block, zeros above the diagonal included (the diagonal blocks
+        // of the block's inverse ARE these: the full inverse stored at the end repeats the same values)
+        {
+          const int i = t & 15, j = t >> 4;
+          const T v = (i >= j) ? Wd[p][wd_idx(i, j)] : T(0);
+          store_sc1(winv + (j0 + i) + (size_t)(j0 + j) * n, v);
+        }
       }
       tA += PH_NOW() - tl;
       tl = PH_NOW();
@@ -2070,7 +2144,11 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
           }
         }
       }
+      if constexpr (FLOW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's panel stores have landed
       __syncthreads();
+      if constexpr (FLOW) {
+        if (t == 0) __hip_atomic_store(fp->fpan, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       tB += PH_NOW() - tl;
     }
     if (ph && t == 0) {
@@ -2078,7 +2156,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       ph[2] = tB;
     }
 #pragma unroll 1
-    for (int c = gc0; c < gc0 + 4; ++c) {
+    for (int c = gc0; c < (FLOW ? gc0 : gc0 + 4); ++c) {  // (FLOW: every panel was stored when it was published)
       if (gr < c) continue;
       T v[16];
       const T *src = S + db_off(gr, c) + (gi & 15);
@@ -2173,6 +2251,348 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag(T *A, int ld, T *__restri
   }
   guest.leave();
   sem_signal(signal_sem);
+}
+
+// ------------------------------------------------------------------------------
+// The tile POTRF of a chain-bound wave as a FLOW (round 4): two persistent launches whose workgroups hand their
+// results on through polled counters, so that nothing but the factorisation of the 128 x 128 diagonal blocks is
+// on the chain -- no kernel boundary, no load, no store of L, no inverse, no in-tile solve / update launch.
+//
+//   k_flow_factor  one workgroup per diagonal block s.  It loads its block, subtracts the products of the earlier
+//                  steps  D_s -= sum_{k<s} X(s,k) X(s,k)^T  itself, 16 columns of X at a time as the row-slab waves
+//                  publish them (the last step's panels arrive while block s-1 is still being factored; only its
+//                  last panel is waited for), factors (potrf_diag_body<FLOW>), publishing every finished 16-column
+//                  panel of L_s and the inverse of its 16 x 16 diagonal block, and ends as k_potrf_diag does
+//                  (inverse of the whole block for the panel TRSM on the other stream, counter D[s]).
+//   k_flow_rows    one WAVE per 16-row slab of the block rows below the first.  At step s it solves its rows of
+//                  block (r, s) against L_s right-looking, one 16-column panel behind the factorisation:
+//                  X_p = A_p W_p^T (W_p = inverse of the panel's diagonal block), A_c -= X_p L_s(c,p)^T, c > p --
+//                  operands straight from global memory into MFMA registers, the slab in accumulators: the
+//                  accumulator of one product IS the B operand of the next (with swapped operands lane (i, q) holds
+//                  X[i][drow(q, r)], r = 0..3, exactly the four k's MFMA r wants when the other operand is fetched
+//                  in the same order), so there is no LDS and no barrier in this kernel.  Then it applies X(r,s) to
+//                  its rows of the blocks (r, c), s < c < r (needs X(c,s) complete), so that block (r, s+1) is
+//                  up to date when step s+1 starts.  It raises I[s] (what the panel TRSM's update on the other
+//                  stream polls) once per step.
+//
+// Chain per 128 columns: the diagonal-block factorisation (phases A + B) + one hand-off each way (last panel ->
+// rows of block s+1 -> rank-16 update of D_{s+1}): 44-50 us measured (profiles/r04_flow_step_stamps.txt) against 72.
+// Why two launches and not one per step: a version with one launch per step and stream (rows, products, the panel
+// TRSM and K = 128 slices of column k+1 all following the factorisation step by step) was built and measured this
+// round -- kernels of a handful of workgroups that follow a long-lived polling kernel start 25-30 us late and
+// their workgroups up to 30 us apart once five queues are active; every such boundary was on the chain.
+//
+// Flow control block `fc` (ints; every counter on a 128-byte line of its own, zeroed by the host):
+//   line 0             abort: a failed pivot or a poll that gave up; every poll watches it, and whoever sees it
+//                      raises the counters the OTHER streams poll (D[s], I[s]) and leaves
+//   line 1 + s         panels of diagonal block s published (0 .. 8)
+//   line 1 + nbm + r nbm + s, ints 0..7   waves of block row r that have published panel p of X(r, s) (0 .. 8)
+// Forward progress: both launches must be resident together (nbm + (mb - 128) / 64 workgroups); the walker uses
+// the form only for the last, chain-bound waves, where the chip is mostly idle, and every poll is bounded.
+// ------------------------------------------------------------------------------
+constexpr int FLOW_SPIN = 1 << 25;
+#ifndef FLOW_POLL_SLEEP
+#define FLOW_POLL_SLEEP 16  // x 64 cycles between two polls of a wave: hundreds of waves poll a handful of lines
+#endif
+__host__ __device__ inline int flow_lines(int nbm, int block_rows) { return 1 + nbm + block_rows * nbm; }
+
+// one lane polls; false: aborted (or gave up: then it raises the abort word itself and reports INT_MAX - 1)
+__device__ __forceinline__ bool flow_wait(const int *ctr, int target, int *fc, int *info, int fences) {
+  int ok = 0;
+  if ((threadIdx.x & 63) == 0) {
+    int i = 0;
+    for (; i < FLOW_SPIN; ++i) {
+      if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+        ok = 1;
+        break;
+      }
+      if ((i & 7) == 7 && __hip_atomic_load(fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      __builtin_amdgcn_s_sleep(FLOW_POLL_SLEEP);
+    }
+    if (i == FLOW_SPIN) {
+      atomicExch(info, 0x7ffffffe);
+      __hip_atomic_store(fc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  ok = __builtin_amdgcn_readfirstlane(ok);
+  if (fences) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" ::: "memory");
+  return ok != 0;
+}
+// the calling wave's stores have landed; then (fences) an agent-scope release
+__device__ __forceinline__ void flow_drain(int fences) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (fences) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+// idx-th lower 16 x 16 block of the 8 x 8 block grid, column by column
+__host__ __device__ constexpr int flow_blk_c(int idx) {
+  int c = 0, len = DB_NP;
+  while (idx >= len) {
+    idx -= len;
+    --len;
+    ++c;
+  }
+  return c;
+}
+__host__ __device__ constexpr int flow_blk_r(int idx) {
+  int c = 0, len = DB_NP;
+  while (idx >= len) {
+    idx -= len;
+    --len;
+    ++c;
+  }
+  return c + idx;
+}
+
+template <typename T, int W>
+__device__ __forceinline__ void flow_rank16(typename Tr<T>::acc_t (&acc)[9], const T (&xf)[8][4], const T (&nxf)[8][4]) {
+  static_for<0, 9>([&](auto Q) {
+    constexpr int q = decltype(Q)::value, idx = W + 4 * q, bi = flow_blk_r(idx), bj = flow_blk_c(idx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q] = Tr<T>::mfma(nxf[bi][r], xf[bj][r], acc[q]);
+  });
+}
+template <typename T, int W>
+__device__ __forceinline__ void flow_fold(const typename Tr<T>::acc_t (&acc)[9], T *S) {
+  const int lane = threadIdx.x & 63, lo = lane & 15;
+  static_for<0, 9>([&](auto Q) {
+    constexpr int q = decltype(Q)::value, idx = W + 4 * q, bi = flow_blk_r(idx), bj = flow_blk_c(idx);
+    T *Cb = S + db_off(bi, bj);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Cb[Tr<T>::drow(lane, reg) + lo * DB_LD] += acc[q][reg];
+  });
+}
+
+// D_s (in L.S) -= sum_{k<s} X(s,k) X(s,k)^T, a 16-column panel of X at a time; false: aborted
+template <typename T>
+__device__ __forceinline__ bool flow_accumulate(const T *tile, int mb, int nbm, int s, int *fc, int *info, int fences,
+                                                DiagLds<T> &L) {
+  using acc_t = typename Tr<T>::acc_t;
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  acc_t acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = T(0);
+  bool ok = true;
+  for (int k = 0; k < s && ok; ++k) {
+    const int *hp = fc + 32 * (1 + nbm + s * nbm + k);
+    if (k < s - 1) ok = flow_wait(hp + 7, 8, fc, info, fences);  // an earlier step: complete long ago
+    for (int p = 0; p < DB_NP && ok; ++p) {
+      if (k == s - 1) ok = flow_wait(hp + p, 8, fc, info, fences);  // the last step: as its panels are published
+      if (!ok) break;
+      // the panel as MFMA fragments, the same registers for both operands: X[16 i + lo][16 p + 4 r + hi]
+      T xf[8][4], nxf[8][4];
+      const T *X = tile + (size_t)(MACRO * s + lo) + (size_t)(MACRO * k + 16 * p + hi) * mb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xf[i][r] = load_sc1(X + 16 * i + (size_t)(4 * r) * mb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxf[i][r] = -xf[i][r];
+      switch (w) {
+        case 0: flow_rank16<T, 0>(acc, xf, nxf); break;
+        case 1: flow_rank16<T, 1>(acc, xf, nxf); break;
+        case 2: flow_rank16<T, 2>(acc, xf, nxf); break;
+        default: flow_rank16<T, 3>(acc, xf, nxf); break;
+      }
+    }
+  }
+  if (ok) {
+    switch (w) {
+      case 0: flow_fold<T, 0>(acc, L.S); break;
+      case 1: flow_fold<T, 1>(acc, L.S); break;
+      case 2: flow_fold<T, 2>(acc, L.S); break;
+      default: flow_fold<T, 3>(acc, L.S); break;
+    }
+  } else if (lane == 0) {
+    L.failed = 3;
+  }
+  __syncthreads();
+  return L.failed == 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_flow_factor(T *tile, int mb, int nbm, T *winv, int *info, int info_base,
+                                                     int *fc, int *ytab, const int *wait_sem, int wait_target,
+                                                     int *dsem, int fences, unsigned long long *dbg) {
+  __shared__ DiagLds<T> L;
+  __shared__ unsigned long long slot_s;
+  const int s = blockIdx.x;
+  sem_wait(wait_sem, wait_target, info);  // the previous wave's last SYRK slice (or null: the stream's order)
+  __builtin_amdgcn_s_setprio(3);
+  unsigned long long t0 = 0;
+  unsigned long long *ph = nullptr;
+  if (dbg) {
+    t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) slot_s = atomicAdd(dbg, 1ull);
+    __syncthreads();
+    if (slot_s < 1000) ph = dbg + 1 + 8 * slot_s + 2;
+  }
+  T *A = tile + (size_t)s * MACRO * (mb + 1);
+  {  // the block as the previous waves' updates left it -> L.S (potrf_diag_body's own loader, see there)
+    constexpr int NB = 16;
+    const int t = threadIdx.x, gi = t & (MACRO - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
+    T v[4][16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = gc0 + q;
+      const T *src = A + gi + (size_t)(NB * c) * mb;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[q][u] = (gr > c || (gr == c && (gi & 15) >= u)) ? src[(size_t)u * mb] : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = gc0 + q;
+      if (gr < c) continue;
+      T *dst = L.S + db_off(gr, c) + (gi & 15);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
+    }
+    if (t == 0) {
+      L.failed = 0;
+      L.colready = 0;
+    }
+    __syncthreads();
+  }
+  bool live = true;
+  if (s > 0) live = flow_accumulate<T>(tile, mb, nbm, s, fc, info, fences, L);
+  if (live) {
+    // a guest of its CU only while it factors (as a diagonal-block launch is for its lifetime): an update workgroup
+    // beside it sleeps for these ~40 us, not for the hundreds this workgroup spends waiting for the earlier steps
+    GuestOnCu guest(ytab);
+    FlowPub<T> fp;
+    fp.fpan = fc + 32 * (1 + s);
+    fp.abort = fc;
+    potrf_diag_body<T, true>(A, mb, winv + (size_t)s * MACRO * MACRO, info, info_base + s * MACRO, 1, L, ph, &fp);
+    guest.leave();
+  }
+  if (ph && threadIdx.x == 0) {
+    ph[-2] = t0;
+    ph[-1] = __builtin_amdgcn_s_memrealtime();
+  }
+  sem_signal(dsem + 32 * s);  // (also when aborted: the TRSM step on the other stream polls it)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_flow_rows(T *tile, int mb, int nbm, const T *winv, int *info, int *fc, int *ytab,
+                                                 const int *wait_sem, int wait_target, int *isem, int fences,
+                                                 unsigned long long *dbg) {
+  using acc_t = typename Tr<T>::acc_t;
+  const unsigned long long t_in = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  sem_wait(wait_sem, wait_target, info);
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
+  const int lane = threadIdx.x & 63, lo = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int R0 = MACRO + 64 * (int)blockIdx.x + 16 * w, rb = R0 >> 7;  // first row of the slab, its block row
+  // column offsets of this lane's four accumulator registers inside a 16 x 16 block (x ld)
+  size_t dcol[4], dcolw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dcol[r] = (size_t)Tr<T>::drow(lane, r) * mb, dcolw[r] = (size_t)Tr<T>::drow(lane, r) * MACRO;
+  acc_t a[8], nxp[8];
+  int signalled = 0;  // steps whose I counter this wave has raised
+  bool live = true;
+  for (int s = 0; s < rb && live; ++s) {
+    T *Ab = tile + (size_t)(R0 + lo) + (size_t)(MACRO * s) * mb;  // my rows of block (rb, s)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[c][r] = Ab[(size_t)(16 * c) * mb + dcol[r]];
+    const T *Ws = winv + (size_t)s * MACRO * MACRO + lo;     // + (16 p) (1 + 128) + dcolw
+    const T *Ls = tile + (size_t)s * MACRO * (mb + 1) + lo;  // diagonal block s: + 16 c + (16 p) mb + dcol
+    const int *fpan = fc + 32 * (1 + s);
+    int *hp = fc + 32 * (1 + nbm + rb * nbm + s);
+    const bool critical = rb == s + 1;  // block row s+1: the next diagonal block waits for these panels one by one
+    static_for<0, 8>([&](auto P) {
+      constexpr int p = decltype(P)::value;
+      if (!live) return;
+      live = flow_wait(fpan, p + 1, fc, info, fences);
+      if (!live) return;
+      T wd[4], lf[8][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wd[r] = load_sc1(Ws + (size_t)(16 * p) * (MACRO + 1) + dcolw[r]);
+#pragma unroll
+      for (int c = p + 1; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lf[c][r] = load_sc1(Ls + 16 * c + (size_t)(16 * p) * mb + dcol[r]);
+      acc_t x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x = Tr<T>::mfma(wd[r], a[p][r], x);  // X_p^T = W_p A_p^T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store_sc1(Ab + (size_t)(16 * p) * mb + dcol[r], x[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nxp[p][r] = -x[r];
+#pragma unroll
+      for (int c = p + 1; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[c] = Tr<T>::mfma(lf[c][r], nxp[p][r], a[c]);  // A_c -= X_p L(c,p)^T
+      if (critical) {
+        flow_drain(fences);
+        if (lane == 0) __hip_atomic_fetch_add(hp + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    });
+    if (!live) break;
+    if (!critical) {
+      flow_drain(fences);
+      if (lane < 8) __hip_atomic_fetch_add(hp + lane, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_fetch_add(isem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    signalled = s + 1;
+    // X(rb, s) onto my rows of the blocks (rb, c), s < c < rb: A[:, c] -= X(rb,s) X(c,s)^T, X(c,s) complete once the
+    // eight waves of block row c have published their last panel.  The fragments of one 16-column output block (its
+    // 8 x 4 operand elements) are requested together, those of the next block behind this one's MFMAs.
+    for (int c = s + 1; c < rb && live; ++c) {
+      live = flow_wait(fc + 32 * (1 + nbm + c * nbm + s) + 7, 8, fc, info, fences);
+      if (!live) break;
+      T *Cb = tile + (size_t)(R0 + lo) + (size_t)(MACRO * c) * mb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[j][r] = Cb[(size_t)(16 * j) * mb + dcol[r]];
+      const T *Xc = tile + (size_t)(MACRO * c + lo) + (size_t)(MACRO * s) * mb;  // block (c, s)
+      T lf[2][8][4];
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lf[0][p][r] = load_sc1(Xc + (size_t)(16 * p) * mb + dcol[r]);
+      static_for<0, 8>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j + 1 < 8) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lf[(j + 1) & 1][p][r] = load_sc1(Xc + 16 * (j + 1) + (size_t)(16 * p) * mb + dcol[r]);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[j] = Tr<T>::mfma(lf[j & 1][p][r], nxp[p][r], a[j]);
+      });
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cb[(size_t)(16 * j) * mb + dcol[r]] = a[j][r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave reads the block back at step c)
+    }
+  }
+  // aborted: the counters the panel TRSM's update on the other stream polls still have to come
+  if (lane == 0)
+    for (int s = signalled; s < rb; ++s) __hip_atomic_fetch_add(isem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  guest.leave();
+  if (blockIdx.x == 0) dbg_mark(dbg, 1, rb, t_in);
 }
 
 // ------------------------------------------------------------------------------
@@ -2387,6 +2807,28 @@ __global__ void k_pad_identity(T *dst, int n, int ldp) {
 // ------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------
+// chol_init's second check: a dispatch that cannot place all its workgroups at once (an update launch of more
+// than one round) keeps the dispatcher of its hardware queue's pipe busy until the last of them is placed, and the
+// kernels of another stream that shares that pipe do not start meanwhile (round 4: workgroups of a four-workgroup
+// launch on the flow's stream seen to start 30 us apart; scripts/exp/pipe_probe.hip).  `big`: four rounds of
+// workgroups (two per CU by LDS) that spin ~20 us each; `small`: one wave, launched right behind it on the other
+// stream, stamps its start.  t[0] = first workgroup of the big launch, t[1] = the small kernel.
+__global__ __launch_bounds__(256) void k_pipe_big(unsigned long long *t, int spin_ticks) {
+  __shared__ char lds[65536];
+  lds[threadIdx.x] = 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) t[0] = t0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(16);
+  if (lds[(threadIdx.x + 1) & 255] == 7) t[2] = 0;
+}
+__global__ void k_pipe_small(unsigned long long *t) {
+  if (threadIdx.x == 0) t[1] = __builtin_amdgcn_s_memrealtime();
+}
+void launch_pipe_probe(hipStream_t big, hipStream_t small, unsigned long long *t, int cus) {
+  k_pipe_big<<<8 * cus, 256, 0, big>>>(t, 2000);
+  k_pipe_small<<<1, 64, 0, small>>>(t);
+}
+
 void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result) {
   k_sem_probe_wait<<<1, 1, 0, consumer>>>(sem, result);
   k_sem_probe_set<<<1, 64, 0, producer>>>(sem);
@@ -2399,6 +2841,13 @@ int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTI
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
 int g_intile_fused_max = 256;  // ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3 (nr <= 10); beyond, resident pollers would queue for CU slots behind each other (CHOLMI_INTILE_FUSED_MAX)
+bool flow_applies(int nbm) { return g_flow && nbm >= g_flow_min_nbm && nbm <= g_flow_max_nbm; }
+int g_flow = 1;          // chain-bound waves: the tile POTRF as a flow of polling workgroups (CHOLMI_FLOW=0: diagonal-block + in-tile step launches)
+int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_MIN_NBM / _MAX_NBM): measured round 4, all waves
+                                             // in flow form against none -- tile 512: +14 ... +17 % (N = 1536 ... 4096), +5 % (N = 5120, 6144); tile 256: -8 %
+                                             // (a two-block tile has one in-tile step to save); tile 1024: -6 ... -12 % (the row waves' products pile up: 21 for the
+                                             // last block row)
+int g_flow_fences = 0;   // ... 1: agent-scope release / acquire around every hand-off of the flow (CHOLMI_FLOW_FENCES; diagnostic)
 int g_poll_max_wgs = 48;  // grids up to this many workgroups poll their counter themselves, larger ones behind a gate (CHOLMI_POLL_MAX_WGS)
 int g_trsm_small_max = 64;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
 int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
@@ -2573,12 +3022,27 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
   // pipe: counters of this wave, one 128-byte slot each -- D[s] the diagonal-block step s, I[s] the in-tile
   // solve of step s (4 nr workgroups), H[s] the head tile's workgroups of TRSM step s, then `done`
   auto slot = [&](int i) { return sy->sem + 32 * i; };
+  // the tile POTRF as a flow (k_flow_factor / k_flow_rows): the diagonal-block steps raise D[s] as before, the
+  // row-slab waves I[s] (8 (nbm - 1 - s) of them instead of the 4 (nbm - 1 - s) workgroups of the in-tile solve)
+  const bool flow = pipe && sy->fc && sy->sflow && flow_applies(nbm);
+  if (flow) {
+    if (sy->join_flow && sy->ev_flow) {  // first flow-form wave: the flow stream joins the POTRF stream's order once (without it the
+                                         // row-slab kernel would sit on the chip, polling, from the moment the host issues it)
+      (void)hipEventRecord(sy->ev_flow, sp);
+      (void)hipStreamWaitEvent(sy->sflow, sy->ev_flow, 0);
+    }
+    k_flow_factor<T><<<nbm, 256, 0, sp>>>(lkk, mb, nbm, winv, d_info, info_base, sy->fc, g_ytab, wait_sem, wait_target,
+                                          slot(0), g_flow_fences, g_dbg);
+    k_flow_rows<T><<<(mb - MACRO) / 64, 256, 0, sy->sflow>>>(lkk, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem,
+                                                           wait_target, slot(nbm), g_flow_fences, g_dbg);
+  }
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
-    k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
-                                       d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
-                                       wait_target, pipe ? slot(s) : nullptr);
-    if (nr > 0) {
+    if (!flow)
+      k_potrf_diag<T><<<1, 256, 0, sp>>>(lkk + (long)s * MACRO * (mb + 1), mb, winv + (long)s * MACRO * MACRO,
+                                         d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
+                                         wait_target, pipe ? slot(s) : nullptr);
+    if (nr > 0 && !flow) {
       if (g_intile_small) {
         if (pipe && g_intile_fused && nr * (2 * nr + 1) <= g_intile_fused_max) {
           // solve and update of the step in one launch, the update's workgroups polling the solves' counter
@@ -2607,7 +3071,7 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       StepSems ss;
       ss.diag = slot(s);
       ss.intile = slot(nbm + s);
-      ss.intile_target = 4 * nr;
+      ss.intile_target = (flow ? 8 : 4) * nr;
       ss.head = slot(2 * nbm + s);
       ss.fail = d_info;
       const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);

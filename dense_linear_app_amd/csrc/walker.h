@@ -91,7 +91,7 @@ struct WaveCalib {
 // switches of the schedule (environment, read once; CHOLMI_* names in DESIGN.md section 4)
 struct WaveSwitches {
   int pair_max_mb = 1024;
-  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, halves_max_rounds = 24.0;
+  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0;
   bool syrk_pipe = true, split_always = false, head_first = true;
   // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
   // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
@@ -102,6 +102,7 @@ struct WaveSwitches {
     if (const char *e = getenv("CHOLMI_PAIR_FACTOR")) pair_fac = atof(e);
     if (const char *e = getenv("CHOLMI_YIELD_FACTOR")) yfac = atof(e);
     if (const char *e = getenv("CHOLMI_PIPE_FACTOR")) pipe_fac = atof(e);
+    if (const char *e = getenv("CHOLMI_FLOW_FACTOR")) flow_fac = atof(e);
     if (const char *e = getenv("CHOLMI_HALVES_MAX_ROUNDS")) halves_max_rounds = atof(e);
     if (const char *e = getenv("CHOLMI_SYRK_PIPE")) syrk_pipe = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_HEAD_FIRST")) head_first = atoi(e) != 0;
@@ -174,7 +175,7 @@ struct Walker {
   PanelRef pan[NBUF];
   int last_lkk[2] = {-1, -1}, last_head[2] = {-1, -1};
   double issue_us = 0, upd_flops = 0;
-  int upd_launches = 0;
+  int upd_launches = 0, flow_waves = 0;
   std::vector<int> halves_waves;
 
   Walker(O &ops, const WaveGeo &geo, WaveComm *comm, const WaveCalib &c) : o(ops), g(geo), cm(comm), cal(c) {}
@@ -327,16 +328,17 @@ struct Walker {
     const auto t_host0 = std::chrono::steady_clock::now();
     const int nt = g.nt, mb = g.mb, nbm = g.nbm, P = g.P, Q = g.Q;
     const bool mr = multi();
-    const int sem_per_wave = 3 * nbm + 1;
+    const int sem_per_wave = 3 * nbm + 1 + flow_ctl_lines(nbm);  // SyrkPipe's counters, then the flow's control block
     WRC(o.begin(E_PER_WAVE * nt + F_FIXED + nbm + 1, nt, sem_per_wave));
     const int ev_steps = fx(F_FIXED);
     WRC(o.rec(fx(F_START), ST_MAIN));
-    for (int st = ST_PANEL; st < (mr ? ST_COUNT : ST_CX); ++st) WRC(o.wt(st, fx(F_START)));  // (their kernels may poll counters zeroed on ST_MAIN)
+    for (int st = ST_PANEL; st < (mr ? ST_COUNT : ST_CX + 1); ++st) WRC(o.wt(st, fx(F_START)));  // (their kernels may poll counters zeroed on ST_MAIN; ST_CX: the flow's row-slab kernel)
     bool paired = false, cols_pending = false, had_pairs = false;
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
-    bool prev_halves = false;
+    bool prev_halves = false, prev_flow = false;
     const bool flags = !mr && o.counters();
+    const bool flow_run = (double)g.tiles_in(1, nt) * cal.t_tile < sw.pipe_fac * cal.t_panel;
     const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
     int wait_target = 0;
     const double b3 = (double)mb * mb * mb;
@@ -352,7 +354,6 @@ struct Walker {
       // the other ranks of the process column solve theirs once L(k,k) has arrived  (C2:510-535)
       // (ST_TRSM needs no event for the start of the wave: its first step waits for the event recorded on
       // ST_PANEL behind the first diagonal-block step, and a record on ST_PANEL costs the chain ~7 us)
-      if (k > 0 && in_col) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
       const int local_tiles = g.tiles_in(k + 1, nt);  // this rank's tiles of wave k's update
       const bool pair_first = k >= sw.pair_start && ((k - sw.pair_start) & 1) == 0;
       if (pair_first)
@@ -364,6 +365,13 @@ struct Walker {
       const bool plain_yield = (double)local_tiles * t_tile < sw.yfac * t_panel;
       const bool chain_bound = (double)local_tiles * t_tile < sw.pipe_fac * t_panel;
       const bool pipe = sw.syrk_pipe && flags && !paired && !last && o.pipe_ok() && plain_yield && chain_bound;
+      // ... with its tile POTRF as a flow (kernels.hip: k_flow_factor) when the WHOLE factorisation is chain-bound (wave 0
+      // already is): measured round 4, the form gains 14-17 % there (tile 512, N <= 4096) and nothing when only the last
+      // waves of a larger matrix use it -- the wave that switches forms pays ~90 us, the rest gains ~40 us each
+      // (CHOLMI_FLOW_FACTOR = f > 0: instead, every wave whose update is shorter than f panel estimates)
+      const bool flow = pipe && own_diag && cntm > 0 && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm) &&
+                        (sw.flow_fac > 0 ? (double)local_tiles * t_tile < sw.flow_fac * t_panel : flow_run);
+      if (k > 0 && in_col) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
       // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite its
       // set while TRSM(k) still reads the other
       const char *head = nullptr;
@@ -377,6 +385,12 @@ struct Walker {
           sy.c = o.tile((k + 1) / P, (k + 1) / Q);
           sy.su = (hipStream_t)o.stream(ST_U1);
           sy.sem = o.sem(k, 0, sem_per_wave);
+          if (flow) {
+            sy.fc = o.sem(k, 3 * nbm + 1, sem_per_wave);
+            sy.sflow = (hipStream_t)o.stream(ST_CX);
+            sy.ev_flow = (hipEvent_t)o.flow_event();
+            sy.join_flow = !prev_flow;
+          }
         }
         // the head tile is this rank's first panel tile only when there is one process row
         const bool head_mine = !last && P == 1;
@@ -405,6 +419,8 @@ struct Walker {
       // last slice's counter, which also stands behind TRSM(k) (same stream, earlier), so POTRF(k+2) may
       // reuse TRSM(k)'s workspace
       const bool by_flags = pipe;
+      prev_flow = flow;
+      if (flow) ++flow_waves;
       wait_sem = by_flags ? o.sem(k, 3 * nbm, sem_per_wave) : nullptr;
       wait_target = (mb / 64) * (mb / 64 + 1) / 2;
       // TRSM(k) complete on this rank
@@ -619,7 +635,7 @@ struct Walker {
     issue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
     // join every stream into ST_MAIN
     const int joins[5][2] = {{F_JOIN, ST_PANEL}, {F_TRSM, ST_TRSM}, {F_U1END, ST_U1}, {F_CX, ST_CX}, {F_PX, ST_PX}};
-    for (int i = 0; i < (mr ? 5 : 3); ++i) {
+    for (int i = 0; i < (mr ? 5 : 4); ++i) {  // (one GPU: ST_CX carries the flow's row-slab kernel)
       WRC(o.rec(fx(joins[i][0]), joins[i][1]));
       WRC(o.wt(ST_MAIN, fx(joins[i][0])));
     }

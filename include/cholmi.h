@@ -235,6 +235,10 @@ int chol_debug_stamps(int enable, unsigned long long *out, int max_pairs);
  * rate this chip sustains under load, to quote beside the datasheet peak. */
 int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);
 
+/* Diagnostic: how many waves of the last whole-matrix chol_potrf_tile factored their diagonal tile in the flow form
+ * (two persistent launches handing 16-column panels to each other through polled counters). */
+int chol_debug_flow_waves(void);
+
 /* What the walker's regime switches (pairs / halves / counter-linked chain / CU hand-over) are measured in,
  * taken once at chol_init (or from CHOLMI_CALIB="tf64,us64,tf32,us32"): out8[0..3] = fp64 MFMA probe
  * [TFLOP/s], fp64 128 x 128 diagonal-block step alone [us], the same for fp32; out8[4..7] = the derived

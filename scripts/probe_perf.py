@@ -18,10 +18,15 @@ def run(N, B, reps=3, dtype=None, check=True):
         info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)
         dt = time.perf_counter() - t0
         st = ch.last_potrf_stats()
+        try:
+            from dense_linear_app_amd import distributed as _dd
+            st["issue"] = _dd.dist_last_stats()["issue_us_per_wave"]
+        except Exception:
+            st["issue"] = -1.0
         if r > 0:
             best = min(best, dt)
         print(f"N={N} B={B} {'f32' if dtype == ch.ChamRealFloat else 'f64'} rep={r} info={info} wall={dt*1e3:.2f} ms dev={st['total_ms']:.2f} ms "
-              f"{N**3/3/dt/1e12:.2f} TF/s  upd_ms={st['update_ms']:.2f} upd_tf={st['update_flops']/max(st['update_ms'],1e-9)/1e9:.2f}", flush=True)
+              f"{N**3/3/dt/1e12:.2f} TF/s  upd_ms={st['update_ms']:.2f} upd_tf={st['update_flops']/max(st['update_ms'],1e-9)/1e9:.2f} host_issue_us_per_wave={st['issue']:.0f}", flush=True)
     if check:
         print("  residual", ch.residual_plgsy(d, float(N), 42), flush=True)
     ch.CHAMELEON_Desc_Destroy(d)

@@ -413,6 +413,84 @@ def test_walker_schedule_variants_match_the_oracle(env, orc):
     assert np.abs(np.tril(Ls).astype(np.float64) - Lref).max() / np.abs(Lref).max() <= 1e-4
 
 
+FLOW_ALL = {"CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}
+
+
+@pytest.mark.parametrize("N,B,env", [
+    (3072, 512, FLOW_ALL),                                         # four 128-blocks per tile, every wave in flow form
+    (3072, 384, FLOW_ALL),                                         # three
+    (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_FENCES="1")),           # ... with release / acquire fences around every hand-off
+    (4096, 1024, dict(FLOW_ALL, CHOLMI_FLOW_MAX_NBM="8")),         # eight blocks per tile (off by default: measured slower)
+    (2048, 256, dict(FLOW_ALL, CHOLMI_FLOW_MIN_NBM="2")),          # two
+    (4096, 512, {"CHOLMI_FLOW_FACTOR": "0.05"}),                   # entered late: event-linked, counter-linked, then flow waves
+    (4096, 512, {}),                                               # the default rule: chain-bound from wave 0 on -> flow
+])
+def test_flow_form_of_the_tile_potrf_matches_the_oracle(N, B, env, orc):
+    """k_flow_factor / k_flow_rows (round 4): the tile POTRF of a counter-linked wave as two persistent launches whose
+    workgroups hand panels of 16 columns to each other through polled counters and write-through stores.  Forced on for
+    every wave (and entered late, and by its default rule) in a fresh process; factor vs the oracle's, element by
+    element, fp64 and fp32; the library must say that the form was actually used."""
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with tempfile.TemporaryDirectory() as tmp:
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from dense_linear_app_amd import chameleon as ch\n"
+            "from dense_linear_app_amd._lib import lib\n"
+            "ch.CHAMELEON_Init(1, 1)\n"
+            "for name, dt in (('d', ch.ChamRealDouble), ('s', ch.ChamRealFloat)):\n"
+            "    d = ch.CHAMELEON_Desc_Create(None, dt, %d, %d, %d, %d, %d, 0, 0, %d, %d, 1, 1)\n"
+            "    ch.CHAMELEON_dplgsy_Tile(float(%d), ch.ChamLower, d, 42)\n"
+            "    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)\n"
+            "    np.save(%r + '/L' + name + '.npy', d.to_lapack()); print(name, info, 'flow_waves', lib().chol_debug_flow_waves())\n"
+        ) % (root, B, B, B * B, N, N, N, N, N, tmp)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "d 0" in r.stdout and "s 0" in r.stdout, (r.stdout, r.stderr[-2000:])
+        used = [int(ln.split()[-1]) for ln in r.stdout.splitlines() if "flow_waves" in ln]
+        assert len(used) == 2 and min(used) >= 1, r.stdout
+        Ld, Ls = np.load(tmp + "/Ld.npy"), np.load(tmp + "/Ls.npy")
+    T = orc.plgsy_tiles(N // B, B, float(N), 42)
+    assert orc.tiled_potrf(T, N // B, B) == 0
+    Lref = np.tril(orc.tile_to_lapack(T, N, B))
+    assert np.abs(np.tril(Ld) - Lref).max() / np.abs(Lref).max() <= 1e-12
+    assert np.abs(np.tril(Ls).astype(np.float64) - Lref).max() / np.abs(Lref).max() <= 1e-4
+
+
+def test_flow_form_reports_a_failed_pivot_and_ends(orc):
+    """A pivot that is not positive (and a NaN) inside a flow-form wave: the diagonal-block workgroup raises the flow's
+    abort word, every polling workgroup of both launches leaves, the counters the other streams poll still come, and
+    chol_potrf_tile returns LAPACK's info -- at once, not after a poll's bound."""
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from dense_linear_app_amd import chameleon as ch\n"
+        "from dense_linear_app_amd._lib import lib\n"
+        "ch.CHAMELEON_Init(1, 1)\n"
+        "N, B = 3072, 512\n"
+        "for what, g, v in (('neg', 1300, -5.0), ('nan', 1801, float('nan')), ('ok', 0, None)):\n"
+        "    d = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, 1, 1)\n"
+        "    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)\n"
+        "    if v is not None:\n"
+        "        t = d.download_tile(g // B, g // B); t[g %% B, g %% B] = v; d.upload_tile(g // B, g // B, t)\n"
+        "    info = ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d)\n"
+        "    print(what, info, 'flow_waves', lib().chol_debug_flow_waves())\n"
+    ) % root
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **FLOW_ALL), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    out = dict((ln.split()[0], int(ln.split()[1])) for ln in r.stdout.splitlines() if "flow_waves" in ln)
+    assert out == {"neg": 1301, "nan": 1802, "ok": 0}, r.stdout
+    assert time.time() - t0 < 120
+
+
 def test_two_processes_factorising_on_one_gpu_do_not_starve_each_other():
     """The counter-linked form of a chain-bound wave launches consumer kernels ahead of time and lets them poll.
     Large polling grids once held so much LDS that the kernel they waited for found no CU -- a deadlock until the

@@ -307,6 +307,12 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
             g = find(guest % t)
             assert g["vgprs"] + per_simd * upd["vgprs"] <= 512, (guest % t, g, upd)
             assert g["lds"] + upd["lds"] <= 160 * 1024, (guest % t, g, upd)
+    # the flow form of the tile POTRF (round 4) is only used for factorisations that are chain-bound from their first
+    # wave on, i.e. on a mostly idle chip: its two kernels need not fit beside an update workgroup, but a workgroup of
+    # each must fit on one CU together (one wave per SIMD each, the factor's LDS)
+    for t in ("d", "f"):
+        ff, fr = find("k_flow_factorI%sE" % t), find("k_flow_rowsI%sE" % t)
+        assert ff["vgprs"] <= 512 and fr["vgprs"] <= 512 and ff["lds"] + fr["lds"] <= 160 * 1024
     # the four-wave kernels stay selectable (CHOLMI_VARIANT=0, CHOLMI_F32_W8=0): same budget
     for name, diag in (("k_trail_updateIdLb1ELb0E", "k_potrf_diagIdE"), ("k_trail_updateIfLb1ELb0E", "k_potrf_diagIfE")):
         upd = find(name)
