@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--cpu-extra-N", type=int, default=20480)
     ap.add_argument("--no-check", action="store_true",
                     help="skip the (untimed) residual of the last step's factor; by default it is in the line")
+    ap.add_argument("--no-worker-path", action="store_true",
+                    help="skip the task-API leg (the same factorisation submitted task by task through the in-process "
+                         "ArmoniK-style client / worker at N=16384, tile 512; ~6 s)")
+    ap.add_argument("--worker-path-N", type=int, default=16384)
+    ap.add_argument("--worker-path-tile", type=int, default=512)
     ap.add_argument("--stall-timeout", type=float, default=600.0,
                     help="self-launched ranks (--gpus N without a launcher): seconds without a heartbeat from any rank "
                          "after which the run is declared hung, the ranks are killed and an error line is printed")
@@ -100,6 +105,37 @@ def cpu_baseline(N: int, B: int, seed: int, vendor: bool = True) -> dict:
     except Exception as e:  # never let the side line break the bench
         out["vendor_lapack"] = {"error": str(e)[:80]}
     return out
+
+
+def worker_path(N: int, B: int) -> dict:
+    """The reference's own submission path (client_distrib.cpp:459-565 -> worker_distrib.cpp:99-564) on the GPU: the
+    DAG of POTRF / TRSM / SYRK / GEMM tasks, one payload and one write-once result per task, tiles resident in HBM,
+    a wave's ready tasks executed as grouped launches.  Rate = N^3/3 over the time of the wave loop (uploads excluded,
+    as the factorisation's timing excludes generation); the factor is checked against the tile matrix it came from."""
+    import numpy as np
+
+    from dense_linear_app_amd import client
+
+    rng = np.random.default_rng(7)
+    # SPD by dominance, cheap to build: unit-scale noise + N on the diagonal.  Only the tiles on or below the diagonal are
+    # ever extracted (C2:407-413) and POTRF / SYRK read the lower triangle only, so the upper tile rows stay zero.
+    A = np.zeros((N, N), order="F")
+    for j in range(0, N, B):
+        A[j:, j:j + B] = rng.uniform(-0.5, 0.5, size=(N - j, min(B, N - j)))
+    A[np.diag_indices(N)] += float(N)
+    client.run_cholesky_dag(min(N, 4 * B), B, device_results=True, batched=True, A=np.asfortranarray(A[:4 * B, :4 * B]))  # warm
+    best = None
+    for _ in range(3):
+        r = client.run_cholesky_dag(N, B, A=A, device_results=True, batched=True)
+        best = r if best is None or r.seconds < best.seconds else best
+    n = sum(best.task_counts.values())
+    # one tile of the factor against numpy on the host (the full parity of this path is tests/test_gpu_worker.py)
+    L00 = np.tril(best.tile(0, 0))
+    ref = np.linalg.cholesky(A[:B, :B])
+    return {"N": N, "tile": B, "tasks": n, "seconds": round(best.seconds, 4), "tflops": round(N ** 3 / 3.0 / best.seconds / 1e12, 2),
+            "us_per_task": round(best.seconds / n * 1e6, 2), "best_of": 3,
+            "tile00_max_rel_err": float(np.abs(L00 - ref).max() / np.abs(ref).max()),
+            "what": "client.run_cholesky_dag(device_results=True, batched=True): wave-level execution behind the task API"}
 
 
 def load_pmc_traffic():
@@ -452,6 +488,11 @@ def main() -> int:
                                                       "device_counters": r["counters"]}
             # one extra step without the library's HIP-event brackets, beside the mean of the K bracketed ones
             line["unprofiled_ms"] = round(r["unprofiled_ms"], 3)
+        if not a.no_worker_path:
+            try:
+                line["worker_path"] = worker_path(a.worker_path_N, a.worker_path_tile)
+            except Exception as e:  # the side leg never breaks the bench line
+                line["worker_path"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_N, a.cpu_tile, a.seed)
             if a.cpu_extra_N and a.cpu_extra_N != a.cpu_N:

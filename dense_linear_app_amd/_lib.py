@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         "chol_make_spd_like_chameleon": ([vp, i, i, d, C.c_char, u64], None),
         "chol_enforce_strict_diag_dominance": ([vp, i, i, d], None),
         "chol_extract_block": ([vp, i, i, i, i, i, vp], None),
+        "chol_parse_payloads": ([C.c_char_p, vp, i, vp, vp, vp, vp], i),
+        "chol_debug_flow_waves": ([], i),
         "chol_last_potrf_stats": ([C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(d)], i),
         "chol_set_profiling": ([i], i),
         "chol_debug_stamps": ([i, C.POINTER(C.c_ulonglong), i], i),

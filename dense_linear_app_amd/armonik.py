@@ -110,11 +110,14 @@ class DeviceBlob:
     pending_epoch = 0  # grouped launches issued on the library's stream so far
     synced_epoch = 0   # ... and how many of them a chol_sync() has since waited for
 
-    def __init__(self, tensor, offset: int = 0, count: Optional[int] = None, epoch: int = 0):
+    __slots__ = ("_parent", "_offset", "nbytes", "ptr", "epoch", "_view")
+
+    def __init__(self, tensor, offset: int = 0, count: Optional[int] = None, epoch: int = 0, base_ptr: Optional[int] = None):
         self._parent = tensor  # 1-D torch tensor on the GPU (owns the memory)
         self._offset = offset  # in bytes
         self.nbytes = tensor.numel() * tensor.element_size() if count is None else count
-        self.ptr = tensor.data_ptr() + offset
+        # (base_ptr: the parent's address when the caller already has it -- a grouped launch makes hundreds of blobs)
+        self.ptr = (tensor.data_ptr() if base_ptr is None else base_ptr) + offset
         self.epoch = epoch
         self._view = tensor if (offset == 0 and count is None) else None
 
@@ -166,21 +169,39 @@ class _Done:
 
 # ------------------------------------------------------------------------------ worker side
 class TaskHandler:
+    __slots__ = ("_plane", "_session", "_task", "_deps")
+
     def __init__(self, plane: "ControlPlane", session_id: str, task: "_Task"):
         self._plane, self._session, self._task = plane, session_id, task
-        self._deps = {rid: plane._results[rid].data for rid in task.data_dependencies}
+        self._deps = None  # built when first asked for (the wave-level path of the worker looks its few ids up itself)
 
     def getPayload(self) -> str:
+        return self.payload_bytes().decode("utf-8")
+
+    def payload_bytes(self) -> bytes:
+        """The payload as the bytes it was uploaded as (getPayload without the copy and the decoding)."""
         data = self._plane._results[self._task.payload_id].data
         if isinstance(data, DeviceBlob):
             data = data.to_bytes()
-        return bytes(data).decode("utf-8")
+        return data if isinstance(data, bytes) else bytes(data)
 
     def getExpectedResults(self) -> List[str]:
         return list(self._task.expected_output_keys)
 
     def getDataDependencies(self) -> Dict[str, bytes]:
+        if self._deps is None:
+            res = self._plane._results
+            self._deps = {rid: res[rid].data for rid in self._task.data_dependencies}
         return self._deps
+
+    def dependency(self, result_id: str):
+        """getDataDependencies().get(result_id) without building the map."""
+        if self._deps is not None:
+            return self._deps.get(result_id)
+        return self._plane._results[result_id].data if result_id in self._task.data_dependencies else None
+
+    def first_expected_result(self) -> str:
+        return self._task.expected_output_keys[0]
 
     def getSessionId(self) -> str:
         return self._session
@@ -209,26 +230,25 @@ class ArmoniKWorker:
 
 
 # ------------------------------------------------------------------------------ control plane
-@dataclass
 class _Result:
-    result_id: str
-    name: str
-    session_id: str
-    data: Optional[bytes] = None
-    status: str = "created"  # created | completed | aborted
+    __slots__ = ("result_id", "name", "session_id", "data", "status")
+
+    def __init__(self, result_id: str, name: str, session_id: str):
+        self.result_id, self.name, self.session_id = result_id, name, session_id
+        self.data = None
+        self.status = "created"  # created | completed | aborted
 
 
-@dataclass
 class _Task:
-    task_id: str
-    session_id: str
-    payload_id: str
-    expected_output_keys: List[str]
-    data_dependencies: List[str]
-    options: TaskOptions
-    status: str = "pending"  # pending | completed | error
-    output: Optional[ProcessStatus] = None
-    attempts: int = 0
+    __slots__ = ("task_id", "session_id", "payload_id", "expected_output_keys", "data_dependencies", "options", "status",
+                 "output", "attempts")
+
+    def __init__(self, task_id, session_id, payload_id, expected_output_keys, data_dependencies, options):
+        self.task_id, self.session_id, self.payload_id = task_id, session_id, payload_id
+        self.expected_output_keys, self.data_dependencies, self.options = expected_output_keys, data_dependencies, options
+        self.status = "pending"  # pending | completed | error
+        self.output = None
+        self.attempts = 0
 
 
 class ControlPlane:
@@ -262,8 +282,13 @@ class ControlPlane:
         r.status = "completed"
 
     def _ready(self, t: _Task) -> bool:
-        need = [t.payload_id] + t.data_dependencies
-        return all(self._results[r].status == "completed" for r in need)
+        res = self._results
+        if res[t.payload_id].status != "completed":
+            return False
+        for r in t.data_dependencies:
+            if res[r].status != "completed":
+                return False
+        return True
 
     def _blocked_forever(self, t: _Task) -> bool:
         need = [t.payload_id] + t.data_dependencies
@@ -328,10 +353,18 @@ class ControlPlane:
                     if self.on_task_done:
                         self.on_task_done(t)
             return
+        res, ok_status, executed, done_cb = self._results, ProcessStatus.Ok, self.executed, self.on_task_done
         for t, status in zip(tasks, statuses):
             t.attempts += 1
             t.output = status
-            missing = [k for k in t.expected_output_keys if self._results[k].status != "completed"]
+            keys = t.expected_output_keys
+            if status is ok_status and len(keys) == 1 and res[keys[0]].status == "completed":  # (the common case, spelled out)
+                t.status = "completed"
+                executed.append(t.task_id)
+                if done_cb:
+                    done_cb(t)
+                continue
+            missing = [k for k in keys if res[k].status != "completed"]
             if status.ok() and not missing:
                 t.status = "completed"
             else:
@@ -369,21 +402,34 @@ class ControlPlane:
                 self._results[k].data = None
                 aborted.add(k)
 
+    def flush_quiet(self) -> bool:
+        """Wait for the workers' asynchronous launches WITHOUT consuming what they found out (a later flush() still
+        reports it).  -> False if a failure is pending."""
+        ok = True
+        for w in self._workers.values():
+            if hasattr(w, "sync"):
+                ok = w.sync() and ok
+        return ok
+
     def _pump(self) -> None:
         progressed = True
         while progressed:
             progressed = False
-            if self.batch_ready:
-                ready = [self._tasks[tid] for tid in self._pending if self._ready(self._tasks[tid])]
+            if self.batch_ready and self._pending:
                 by_part: Dict[str, List[_Task]] = {}
-                for t in ready:
-                    by_part.setdefault(t.options.partition_id, []).append(t)
-                for part, ts in by_part.items():
-                    if ts and hasattr(self._workers.get(part), "ExecuteBatch"):
-                        for t in ts:
-                            self._pending.remove(t.task_id)
+                rest = []
+                tasks, ready_fn, workers = self._tasks, self._ready, self._workers
+                for tid in self._pending:  # one pass: the ready tasks of partitions with a batch-capable worker leave the list
+                    t = tasks[tid]
+                    if ready_fn(t) and hasattr(workers.get(t.options.partition_id), "ExecuteBatch"):
+                        by_part.setdefault(t.options.partition_id, []).append(t)
+                    else:
+                        rest.append(tid)
+                if by_part:
+                    self._pending = rest
+                    for ts in by_part.values():
                         self._run_batch(ts)
-                        progressed = True
+                    progressed = True
             for tid in list(self._pending):
                 t = self._tasks[tid]
                 if self._blocked_forever(t):
@@ -434,6 +480,30 @@ class ResultsClient:
         self._plane._complete_result(result_id, data)
         self._plane._pump()
 
+    def upload_results_data(self, session_id: str, items: Dict[str, object]) -> None:
+        """upload_result_data for several results in one call (one gRPC stream in the SDK's bulk uploads): the tasks
+        they complete the inputs of are looked at once, at the end."""
+        plane = self._plane
+        for result_id, data in items.items():
+            if isinstance(data, str):
+                data = data.encode("utf-8")
+            name = plane._results[result_id].name if result_id in plane._results else ""
+            if plane.device_results and not name.startswith("payload") and not isinstance(data, DeviceBlob):
+                data = DeviceBlob.from_bytes(data)
+            plane._complete_result(result_id, data)
+        plane._pump()
+
+    def delete_results_data(self, session_id: str, result_ids: Iterable[str]) -> None:
+        """ResultsClient.delete_results_data of the SDK: the data behind the ids is released, the metadata stays (status
+        "deleted": downloading it, or submitting a task that depends on it, fails).  The caller vouches that nothing that
+        reads the data is still running -- for device blobs written or read by asynchronous grouped launches that means
+        a worker flush / chol_sync first (client.run_cholesky_dag does exactly that)."""
+        results = self._plane._results
+        for rid in result_ids:
+            r = results[rid]
+            r.data = None
+            r.status = "deleted"
+
     def download_result_data(self, session_id: str, result_id: str) -> bytes:
         r = self._plane._results[result_id]
         if r.status != "completed":
@@ -450,14 +520,19 @@ class TasksClient:
         opts = task_options or self._plane._sessions[session_id]
         shared = opts.copy()  # (one private copy per submission: the tasks of a call share their options)
         ids = []
+        results, tasks, pending = self._plane._results, self._plane._tasks, self._plane._pending
         for tc in task_creations:
-            for rid in [tc.payload_id, *tc.expected_output_keys, *tc.data_dependencies]:
-                if rid not in self._plane._results:
+            if tc.payload_id not in results:
+                raise KeyError(f"submit_tasks: unknown result id {tc.payload_id}")
+            for rid in tc.expected_output_keys:
+                if rid not in results:
+                    raise KeyError(f"submit_tasks: unknown result id {rid}")
+            for rid in tc.data_dependencies:
+                if rid not in results:
                     raise KeyError(f"submit_tasks: unknown result id {rid}")
             tid = _new_id()
-            self._plane._tasks[tid] = _Task(tid, session_id, tc.payload_id, list(tc.expected_output_keys),
-                                            list(tc.data_dependencies), shared)
-            self._plane._pending.append(tid)
+            tasks[tid] = _Task(tid, session_id, tc.payload_id, list(tc.expected_output_keys), list(tc.data_dependencies), shared)
+            pending.append(tid)
             ids.append(tid)
         self._plane._pump()
         return ids
@@ -472,8 +547,9 @@ class EventsClient:
 
     def wait_for_result_availability(self, session_id: str, result_ids: Sequence[str]) -> None:
         self._plane._pump()
+        results = self._plane._results
         for rid in result_ids:
-            r = self._plane._results[rid]
+            r = results[rid]
             if r.status == "completed":
                 continue
             producer = next((t for t in self._plane._tasks.values() if rid in t.expected_output_keys), None)

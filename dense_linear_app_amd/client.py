@@ -259,46 +259,86 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
         """items: (payload_json, data_deps).  One metadata call, one submission, one wait."""
         if not items:
             return []
-        names = [f"output/{q}" for q in range(len(items))] + [f"payload/{q}" for q in range(len(items))]
-        ids = resultsClient.create_results_metadata(session_id, names)
-        tcs = []
-        for q, (payload_json, data_deps) in enumerate(items):
-            resultsClient.upload_result_data(session_id, ids[f"payload/{q}"], payload_json)
-            tcs.append(ak.TaskCreation(payload_id=ids[f"payload/{q}"], expected_output_keys=[ids[f"output/{q}"]],
-                                       data_dependencies=sorted(set(data_deps))))
+        m = len(items)
+        onames, pnames = [f"output/{q}" for q in range(m)], [f"payload/{q}" for q in range(m)]
+        ids = resultsClient.create_results_metadata(session_id, onames + pnames)
+        outs, pids = [ids[x] for x in onames], [ids[x] for x in pnames]
+        resultsClient.upload_results_data(session_id, {pid: it[0] for pid, it in zip(pids, items)})  # one call, not m
+        tcs = [ak.TaskCreation(pid, [oid], sorted(set(it[1]))) for pid, oid, it in zip(pids, outs, items)]
         opts = taskOptions.copy()
         opts.partition_id = PARTITION
         tasksClient.submit_tasks(session_id, tcs, opts)
-        outs = [ids[f"output/{q}"] for q in range(len(items))]
         eventsClient.wait_for_result_availability(session_id, outs)
         return outs
 
     t0 = time.perf_counter()
     if batched:
+        # The wave loop creates ~10 small objects per task and frees none before the end: the cyclic collector's
+        # full passes over them (and over whatever an earlier run left alive) cost more than the loop itself --
+        # 52 against 121 ms at N=16384, tile 512, measured round 4.  Nothing here forms a cycle; collection is
+        # switched off for the loop and restored after.
+        import gc
+
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane, eventsClient, device_results, t0,
+                                      resultsClient, worker)
+        finally:
+            if gc_was_on:
+                gc.enable()
+    return _run_waves_serial(N, B, Nb, session_id, latest, counts, submit_one, plane, verbose, log, t0)
+
+
+def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane, eventsClient, device_results, t0,
+                       resultsClient=None, worker=None):
+    """C2:506-565, one submission per phase of a wave."""
+    if True:
+        # (the same payload texts as make_payload -- json.dumps with compact separators -- written directly: the ids are
+        # the control plane's own hex ids, nothing in them needs escaping; asserted once below)
+        bid = [[block_id_from_ij(i, j) for j in range(i + 1)] for i in range(Nb)]
+        assert make_payload("GEMM", ["a", "b", "c"], B) == f'{{"op":"GEMM","B":{int(B)},"inC":"a","inAi":"b","inAj":"c"}}'
+        Bi = int(B)
+        # Results are write-once, so every task adds a tile version; with the tiles resident in HBM the superseded
+        # versions have to go, or N=65536 / tile 1024 would hold 45 760 x 8 MiB.  They are released in bulk once
+        # RETIRE_BYTES of them have piled up, behind a wait for the launches that may still read them (chol_sync:
+        # the host is then idle until the GPU has caught up -- rare: never below ~12 000 tile-MiB of versions).
+        retire_limit = int(os.environ.get("CHOLESKY_RETIRE_BYTES", str(24 << 30)))
+        retired, retired_bytes, tile_bytes = [], 0, 8 * Bi * Bi
+        can_retire = device_results and resultsClient is not None and hasattr(worker, "flush")
         for k in range(Nb):
-            kk = block_id_from_ij(k, k)
+            if can_retire and retired_bytes > retire_limit:
+                if plane.flush_quiet():  # (a failed POTRF found on the way: leave everything for the final flush to report)
+                    resultsClient.delete_results_data(session_id, retired)
+                    retired, retired_bytes = [], 0
+                else:
+                    can_retire = False
+            kk = bid[k][k]
+            if can_retire:
+                retired.append(latest[kk])
+                retired.extend(latest[bid[i][j]] for i in range(k + 1, Nb) for j in range(k, i + 1))
+                retired_bytes += tile_bytes * (1 + (Nb - k - 1) * (Nb - k + 2) // 2)
             latest[kk] = submit_batch([(make_payload("POTRF", [latest[kk]], B), [latest[kk]])])[0]
             counts["POTRF"] += 1
             Lkk = latest[kk]
-            rows = list(range(k + 1, Nb))
-            outs = submit_batch([(make_payload("TRSM", [Lkk, latest[block_id_from_ij(i, k)]], B),
-                                  [Lkk, latest[block_id_from_ij(i, k)]]) for i in rows])
+            rows = range(k + 1, Nb)
+            ins = [latest[bid[i][k]] for i in rows]
+            outs = submit_batch([(f'{{"op":"TRSM","B":{Bi},"inL":"{Lkk}","inA":"{a}"}}', [Lkk, a]) for a in ins])
             for i, o in zip(rows, outs):
-                latest[block_id_from_ij(i, k)] = o
-            counts["TRSM"] += len(rows)
+                latest[bid[i][k]] = o
+            counts["TRSM"] += len(outs)
             items, keys = [], []
-            for i in rows:
-                Aik = latest[block_id_from_ij(i, k)]
-                for j in range(k + 1, i + 1):
-                    Cij = latest[block_id_from_ij(i, j)]
-                    if i == j:
-                        items.append((make_payload("SYRK", [Cij, Aik], B), [Cij, Aik]))
-                        counts["SYRK"] += 1
-                    else:
-                        Ajk = latest[block_id_from_ij(j, k)]
-                        items.append((make_payload("GEMM", [Cij, Aik, Ajk], B), [Cij, Aik, Ajk]))
-                        counts["GEMM"] += 1
-                    keys.append(block_id_from_ij(i, j))
+            for i, Aik in zip(rows, outs):
+                row = bid[i]
+                for j in range(k + 1, i):
+                    Cij, Ajk = latest[row[j]], latest[bid[j][k]]
+                    items.append((f'{{"op":"GEMM","B":{Bi},"inC":"{Cij}","inAi":"{Aik}","inAj":"{Ajk}"}}', [Cij, Aik, Ajk]))
+                    keys.append(row[j])
+                Cii = latest[row[i]]
+                items.append((f'{{"op":"SYRK","B":{Bi},"inC":"{Cii}","inA":"{Aik}"}}', [Cii, Aik]))
+                keys.append(row[i])
+                counts["GEMM"] += i - k - 1
+                counts["SYRK"] += 1
             for key, o in zip(keys, submit_batch(items)):
                 latest[key] = o
         if device_results:
@@ -308,6 +348,10 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
             plane.flush()
             eventsClient.wait_for_result_availability(session_id, list(latest.values()))
         return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane)
+
+
+def _run_waves_serial(N, B, Nb, session_id, latest, counts, submit_one, plane, verbose, log, t0):
+    """C2:506-565 as the reference runs it: four blocking calls per task."""
     for k in range(Nb):  # C2:506
         if verbose:
             print(f"Wave k={k}", file=log)

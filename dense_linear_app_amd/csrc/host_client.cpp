@@ -80,4 +80,94 @@ void chol_extract_block(const double *A, int N, int LDA, int B, int bi, int bj, 
       std::memcpy(block + (size_t)jj * B, A + r0 + (size_t)(c0 + jj) * LDA, sizeof(double) * (size_t)rows);
 }
 
+// handle_json (worker_distrib.cpp:47-69) for the n payloads of a wave in one call.  buf: the payloads back to
+// back, payload t = buf[off[t] .. off[t+1]).  Per payload: op[t] = 1 TRSM, 2 SYRK, 3 GEMM, 4 POTRF; B[t]; and for the
+// op's tile ids, in the order the grouped launch takes them -- TRSM {inA, inL}, SYRK {inC, inA}, GEMM {inC, inAi,
+// inAj}, POTRF {in} -- where the id string sits: id_off[3 t + r] (into buf), id_len[3 t + r].
+// op[t] = 0: anything this flat reader does not take (another op, a missing field, an escape inside a string, a
+// number that is not a plain integer, nested values, trailing text): the caller hands THAT payload to its general
+// JSON parser, whose verdict -- including the exception text -- is then the reference's.  Returns 0.
+static inline const char *skip_ws(const char *p, const char *e) {
+  while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+  return p;
+}
+int chol_parse_payloads(const char *buf, const long long *off, int n, int *op, int *B, long long *id_off, int *id_len) {
+  if (!buf || !off || !op || !B || !id_off || !id_len || n < 0) return -1;
+  for (int t = 0; t < n; ++t) {
+    op[t] = 0;
+    B[t] = 0;
+    for (int r = 0; r < 3; ++r) id_off[3 * t + r] = 0, id_len[3 * t + r] = -1;
+    const char *p = buf + off[t], *e = buf + off[t + 1];
+    // fields: 0 op, 1 B, 2 in, 3 inL, 4 inA, 5 inC, 6 inAi, 7 inAj
+    const char *vs[8] = {nullptr};
+    int vl[8] = {0};
+    bool have[8] = {false};
+    long long bval = 0;
+    bool ok = true;
+    p = skip_ws(p, e);
+    if (p >= e || *p != '{') continue;
+    p = skip_ws(p + 1, e);
+    if (p < e && *p == '}') ok = false;
+    while (ok) {
+      if (p >= e || *p != '"') { ok = false; break; }
+      const char *k = ++p;
+      while (p < e && *p != '"' && *p != '\\') ++p;
+      if (p >= e || *p != '"') { ok = false; break; }
+      const int kl = (int)(p - k);
+      p = skip_ws(p + 1, e);
+      if (p >= e || *p != ':') { ok = false; break; }
+      p = skip_ws(p + 1, e);
+      int f = -1;
+      static const char *names[8] = {"op", "B", "in", "inL", "inA", "inC", "inAi", "inAj"};
+      for (int q = 0; q < 8; ++q)
+        if ((int)strlen(names[q]) == kl && !memcmp(names[q], k, kl)) f = q;
+      if (p < e && *p == '"') {
+        const char *v = ++p;
+        while (p < e && *p != '"' && *p != '\\' && (unsigned char)*p >= 0x20) ++p;
+        if (p >= e || *p != '"') { ok = false; break; }
+        if (f == 1) { ok = false; break; }  // B as a string: the general parser's TypeError
+        if (f >= 0) vs[f] = v, vl[f] = (int)(p - v), have[f] = true;
+        ++p;
+      } else if (p < e && (*p == '-' || (*p >= '0' && *p <= '9'))) {
+        const char *v = p;
+        bool neg = *p == '-';
+        if (neg) ++p;
+        if (p >= e || *p < '0' || *p > '9') { ok = false; break; }
+        if (*p == '0' && p + 1 < e && p[1] >= '0' && p[1] <= '9') { ok = false; break; }  // leading zero: not JSON
+        long long x = 0;
+        int digits = 0;
+        while (p < e && *p >= '0' && *p <= '9') x = x * 10 + (*p - '0'), ++p, ++digits;
+        if (digits > 9 || (p < e && (*p == '.' || *p == 'e' || *p == 'E'))) { ok = false; break; }
+        if (f == 1) bval = neg ? -x : x, have[1] = true;
+        else if (f >= 0) { ok = false; break; }  // an id that is a number: str(d[...]) in the general parser
+        (void)v;
+      } else {
+        ok = false;  // true / false / null / nested: the general parser decides
+        break;
+      }
+      p = skip_ws(p, e);
+      if (p < e && *p == ',') { p = skip_ws(p + 1, e); continue; }
+      if (p < e && *p == '}') { p = skip_ws(p + 1, e); ok = p == e; break; }
+      ok = false;
+    }
+    if (!ok || !have[0] || !have[1]) continue;
+    int code = 0;
+    int need[3] = {-1, -1, -1};
+    if (vl[0] == 4 && !memcmp(vs[0], "TRSM", 4)) code = 1, need[0] = 4, need[1] = 3;
+    else if (vl[0] == 4 && !memcmp(vs[0], "SYRK", 4)) code = 2, need[0] = 5, need[1] = 4;
+    else if (vl[0] == 4 && !memcmp(vs[0], "GEMM", 4)) code = 3, need[0] = 5, need[1] = 6, need[2] = 7;
+    else if (vl[0] == 5 && !memcmp(vs[0], "POTRF", 5)) code = 4, need[0] = 2;
+    else continue;
+    bool all = true;
+    for (int r = 0; r < 3; ++r)
+      if (need[r] >= 0 && !have[need[r]]) all = false;
+    if (!all) continue;
+    for (int r = 0; r < 3; ++r)
+      if (need[r] >= 0) id_off[3 * t + r] = vs[need[r]] - buf, id_len[3 * t + r] = vl[need[r]];
+    op[t] = code;
+    B[t] = (int)bval;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -132,6 +132,47 @@ class HipTileBackend:
             ch.CHAMELEON_Desc_Destroy(dAj)
 
 
+    # ---- the grouped launches of ExecuteBatch (wave-level execution)
+    def parse_payloads(self, payloads):
+        """W2:47-69 for a batch: (buffer, op codes, B, id offsets, id lengths) -- chol_parse_payloads."""
+        from ._lib import lib
+
+        n = len(payloads)
+        buf = b"".join(payloads)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, payloads), dtype=np.int64, count=n), out=off[1:])
+        op, Bs = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        io, il = np.empty(3 * n, dtype=np.int64), np.empty(3 * n, dtype=np.int32)
+        rc = lib().chol_parse_payloads(buf, off.ctypes.data, n, op.ctypes.data, Bs.ctypes.data, io.ctypes.data, il.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("chol_parse_payloads failed")
+        return buf, op.tolist(), Bs.tolist(), io.tolist(), il.tolist()
+
+    def sync_inputs(self) -> None:
+        import torch
+
+        torch.cuda.current_stream().synchronize()
+
+    def batch_alloc(self, m: int, B: int):
+        """One allocation for the m output tiles of a grouped launch -> (owner, device address)."""
+        import torch
+
+        res = torch.empty(m * B * B, dtype=torch.float64, device="cuda")
+        return res, res.data_ptr()
+
+    def tile_batch(self, code: int, B: int, m: int, ptr) -> int:
+        from ._lib import lib
+
+        return lib().chol_tile_batch(code, ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[1].ctypes.data,
+                                     ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data,
+                                     ptr[4].ctypes.data if code == 1 else None, 1)
+
+    def potrf_batch(self, B: int, m: int, ptr, slots) -> int:
+        from ._lib import lib
+
+        return lib().chol_potrf_batch(ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[3].ctypes.data, ptr[4].ctypes.data, slots, 1)
+
+
 class _DevTile:
     """A private device copy of a tile blob (the worker mutates copies, W2:212-213)."""
 
@@ -346,99 +387,122 @@ class DagCholeskyWorker(ArmoniKWorker):
         ProcessStatus per task as Execute; the TRSM / SYRK / GEMM tasks whose tiles are HBM-resident (DeviceBlob)
         are issued as ONE grouped launch per op class (chol_tile_batch: bit-identical to the one-tile calls),
         asynchronously -- their results are device blobs ordered on the library's stream.  Everything else
-        (POTRF, host blobs, any task that fails a check) goes through Execute."""
+        (POTRF unless async_potrf, host blobs, any task that fails a check) goes through Execute.
+        The payloads of the batch are read by ONE call of the library's flat reader (chol_parse_payloads: W2:47-69,
+        batched); a payload it does not take goes to handle_json, whose verdict is then reported."""
         import ctypes as C
-
-        import torch
-
-        from ._lib import lib
 
         n = len(handlers)
         out: list = [None] * n
-        if not isinstance(self.backend, HipTileBackend):
+        be = self.backend
+        if not isinstance(be, HipTileBackend):
+            return [self._execute_one(h) for h in handlers]
+        try:
+            payloads = [h.payload_bytes() for h in handlers]
+            buf, ops, Bs, id_off, id_len = be.parse_payloads(payloads)
+        except Exception:  # (a payload that is not even bytes: the one-task path reports it)
             return [self._execute_one(h) for h in handlers]
         groups: dict = {}
-        for idx, h in enumerate(handlers):
+        async_potrf = self.async_potrf
+        for idx in range(n):
+            code, B = ops[idx], Bs[idx]
+            h = handlers[idx]
+            if code <= 0 or B <= 0 or B % 128 or (code == 4 and not async_potrf):
+                out[idx] = self._execute_one(h)  # (other ops, odd tile sizes, unreadable payloads: Execute's own messages)
+                continue
             try:
-                p = handle_json(h.getPayload())
-                code = self._BATCH_OP.get(p.op)
-                if code is None and p.op == "POTRF" and self.async_potrf:
-                    code = 4
-                if code is None or p.B <= 0 or p.B % 128:
-                    out[idx] = self._execute_one(h)
-                    continue
-                names = ((p.inA, p.inL) if code == 1 else (p.inC, p.inA) if code == 2 else (p.inC, p.inAi, p.inAj) if code == 3
-                         else (p.in_,))
-                deps = h.getDataDependencies()
-                blobs = [deps.get(x) for x in names]
-                want = p.B * p.B * 8
-                if any(not isinstance(b, DeviceBlob) or b.nbytes != want for b in blobs):
+                o = 3 * idx
+                want = B * B * 8
+                b0 = h.dependency(buf[id_off[o]:id_off[o] + id_len[o]].decode())
+                ok = isinstance(b0, DeviceBlob) and b0.nbytes == want
+                tag = 0
+                b1 = b2 = None
+                if ok and code != 4:
+                    id1 = buf[id_off[o + 1]:id_off[o + 1] + id_len[o + 1]].decode()
+                    b1 = h.dependency(id1)
+                    ok = isinstance(b1, DeviceBlob) and b1.nbytes == want
+                    if ok and code == 1:
+                        tag = _tag_of(id1)
+                    elif ok and code == 3:
+                        b2 = h.dependency(buf[id_off[o + 2]:id_off[o + 2] + id_len[o + 2]].decode())
+                        ok = isinstance(b2, DeviceBlob) and b2.nbytes == want
+                if not ok:
                     out[idx] = self._execute_one(h)  # (missing / short / host blobs: the one-task path reports them)
                     continue
-                groups.setdefault((code, p.B), []).append((idx, h, blobs, _tag_of(p.inL) if code == 1 else 0))
+                g = groups.get((code, B))
+                if g is None:
+                    g = groups[(code, B)] = ([], [], [], [], [])  # task index, three operand pointers, tag
+                g[0].append(idx)
+                g[1].append(b0.ptr)
+                g[2].append(b1.ptr if b1 is not None else 0)
+                g[3].append(b2.ptr if b2 is not None else 0)
+                g[4].append(tag)
             except Exception as e:  # W2:558-560
                 out[idx] = ProcessStatus("Exception: " + str(e))
         if groups:
-            torch.cuda.current_stream().synchronize()  # uploads made through torch are visible to the library's stream
-        for (code, B), items in groups.items():
-            m = len(items)
-            res = torch.empty(m * B * B, dtype=torch.float64, device="cuda")
-            base, tb = res.data_ptr(), B * B * 8
+            be.sync_inputs()  # uploads made through torch are visible to the library's stream
+        ok_status = ProcessStatus.Ok
+        for (code, B), (idxs, p0, p1, p2, tags) in groups.items():
+            m = len(idxs)
+            tb = B * B * 8
+            res, base = be.batch_alloc(m, B)
             ptr = np.empty((5, m), dtype=np.uint64)
-            for q, (_, _, blobs, tag) in enumerate(items):
-                ptr[0, q] = blobs[0].ptr
-                ptr[1, q] = blobs[1].ptr if code != 4 else 0
-                ptr[2, q] = blobs[2].ptr if code == 3 else 0
-                ptr[4, q] = tag
-            ptr[3, :] = base + tb * np.arange(m, dtype=np.uint64)
+            ptr[0], ptr[1], ptr[2], ptr[4] = p0, p1, p2, tags
+            ptr[3] = np.arange(base, base + tb * m, tb, dtype=np.uint64)
+            order = None
             if code == 4:  # POTRF: enqueued, the output tagged with its result id, info left in a device slot
-                outs = [h.getExpectedResults()[0] for _, h, _, _ in items]
+                outs = [handlers[i].first_expected_result() for i in idxs]
                 ptr[4] = [_tag_of(o) for o in outs]
                 slots = (C.c_int * m)()
                 t0 = time.perf_counter()
-                rc = lib().chol_potrf_batch(ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[3].ctypes.data,
-                                            ptr[4].ctypes.data, slots, 1)
-                self.batches += 1
-                self.batched_tasks += m
-                DeviceBlob.pending_epoch += 1
-                epoch = DeviceBlob.pending_epoch
-                self._perf("POTRF", time.perf_counter() - t0, (1.0 / 3.0) * m * B * B * B)
-                for q, (idx, h, _, _) in enumerate(items):
-                    if rc != 0:
-                        out[idx] = ProcessStatus(f"Exception: [Worker][POTF] dpotrf info={rc}")
-                        continue
-                    try:
-                        h.send_result(outs[q], DeviceBlob(res, q * tb, tb, epoch)).get()
-                        self._deferred.append((outs[q], int(slots[q])))
-                        out[idx] = ProcessStatus.Ok
-                    except Exception as e:
-                        out[idx] = ProcessStatus("[Worker][POTF] send_result failed: " + str(e))
-                continue
-            if code == 1:  # panels: the tasks that share an L side by side
-                order = np.argsort(ptr[1], kind="stable")
-                ptr[:3] = ptr[:3, order]
-                ptr[4] = ptr[4, order]
-                items = [items[int(o)] for o in order]
-            t0 = time.perf_counter()
-            rc = lib().chol_tile_batch(code, ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[1].ctypes.data,
-                                       ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data,
-                                       ptr[4].ctypes.data if code == 1 else None, 1)
+                rc = be.potrf_batch(B, m, ptr, slots)
+                opname, flops = "POTRF", (1.0 / 3.0) * m * B * B * B
+            else:
+                if code == 1:  # panels: the tasks that share an L side by side
+                    order = np.argsort(ptr[1], kind="stable")
+                    ptr[:3] = ptr[:3, order]
+                    ptr[4] = ptr[4, order]
+                    idxs = [idxs[int(o)] for o in order]
+                t0 = time.perf_counter()
+                rc = be.tile_batch(code, B, m, ptr)
+                opname = ("", "TRSM", "SYRK", "GEMM")[code]
+                flops = (1.0, 1.0, 1.0, 2.0)[code] * m * B * B * B
             self.batches += 1
             self.batched_tasks += m
             DeviceBlob.pending_epoch += 1
             epoch = DeviceBlob.pending_epoch
-            opname = ("", "TRSM", "SYRK", "GEMM")[code]
-            self._perf(opname, time.perf_counter() - t0, (1.0, 1.0, 1.0, 2.0)[code] * m * B * B * B)
-            for q, (idx, h, _, _) in enumerate(items):
-                if rc != 0:
-                    out[idx] = ProcessStatus(f"Exception: [Worker][{opname}] d{opname.lower()} info={rc}")
-                    continue
+            self._perf(opname, time.perf_counter() - t0, flops)
+            if rc != 0:
+                msg = f"Exception: [Worker][{'POTF' if code == 4 else opname}] d{opname.lower()} info={rc}"
+                for i in idxs:
+                    out[i] = ProcessStatus(msg)
+                continue
+            for q, i in enumerate(idxs):
+                h = handlers[i]
                 try:
-                    h.send_result(h.getExpectedResults()[0], DeviceBlob(res, q * tb, tb, epoch)).get()
-                    out[idx] = ProcessStatus.Ok
+                    oid = outs[q] if code == 4 else h.first_expected_result()
+                    h.send_result(oid, DeviceBlob(res, q * tb, tb, epoch, base)).get()
+                    if code == 4:
+                        self._deferred.append((oid, int(slots[q])))
+                    out[i] = ok_status
                 except Exception as e:
-                    out[idx] = ProcessStatus("send_result failed: " + str(e))
+                    out[i] = ProcessStatus(("[Worker][POTF] " if code == 4 else "") + "send_result failed: " + str(e))
         return out
+
+    def sync(self) -> bool:
+        """Wait for everything ExecuteBatch enqueued; -> False if an asynchronously factored tile has failed (flush()
+        will report which)."""
+        import ctypes as C
+
+        from ._lib import lib
+
+        lib().chol_sync()
+        DeviceBlob.synced_epoch = DeviceBlob.pending_epoch
+        for _, slot in self._deferred:
+            info = C.c_int()
+            if lib().chol_batch_info(slot, C.byref(info)) != 0 or info.value != 0:
+                return False
+        return True
 
     def flush(self) -> list:
         """Wait for everything ExecuteBatch enqueued and collect what it could not know when it reported:

@@ -204,6 +204,12 @@ int chol_residual_plgsy_inf(chol_desc_t *L, double bump, unsigned long long seed
 void chol_make_spd_like_chameleon(double *A, int N, int LDA, double bump, char uplo,
                                   unsigned long long seed);
 void chol_enforce_strict_diag_dominance(double *A, int N, int LDA, double eps);
+/* handle_json W2:47-69 for the n payloads of a wave in one call (the worker's wave-level execution):
+ * buf = the payloads back to back, payload t = buf[off[t] .. off[t+1]).  op[t]: 1 TRSM, 2 SYRK, 3 GEMM, 4 POTRF, B[t],
+ * and id_off / id_len [3 t + r]: where the op's tile ids sit in buf, in the order chol_tile_batch takes them (TRSM
+ * {inA, inL}, SYRK {inC, inA}, GEMM {inC, inAi, inAj}, POTRF {in}).  op[t] = 0: not a flat payload of these four ops
+ * -- the caller's general JSON parser decides about it, with the reference's messages.  Host only. */
+int chol_parse_payloads(const char *buf, const long long *off, int n, int *op, int *B, long long *id_off, int *id_len);
 /* extract_block_from_spd_matrix_colmajor C2:280-309 */
 void chol_extract_block(const double *A, int N, int LDA, int B, int bi, int bj, double *block);
 

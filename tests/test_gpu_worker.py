@@ -139,6 +139,28 @@ def test_wave_level_execution_is_bit_identical_to_the_per_task_path(cham, orc, N
     assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-13
 
 
+def test_wave_level_client_releases_superseded_tile_versions(cham, orc, monkeypatch):
+    """Results are write-once, so every task adds a tile version; the wave-level client releases the superseded ones
+    (ResultsClient.delete_results_data behind a wait for the launches that may still read them) once enough have piled
+    up.  Forced after every wave here: same bits, and only the final versions still hold data."""
+    from dense_linear_app_amd import armonik as ak, client
+
+    N, B = 2048, 256
+    plain = client.run_cholesky_dag(N, B, device_results=True, batched=True)
+    monkeypatch.setenv("CHOLESKY_RETIRE_BYTES", "1")
+    lean = client.run_cholesky_dag(N, B, device_results=True, batched=True)
+    assert np.array_equal(lean.lower_factor(), plain.lower_factor())
+    res = lean.plane._results
+    final = set(lean.latest.values())
+    held = [rid for rid, r in res.items() if isinstance(r.data, ak.DeviceBlob)]
+    deleted = [rid for rid, r in res.items() if r.status == "deleted"]
+    assert set(held) >= final and len(deleted) > 100
+    # (the last waves' superseded versions wait for a release that never came: bounded by what two waves produce)
+    assert len(held) - len(final) <= 3 * (N // B) ** 2 // 2
+    with pytest.raises(ak.ResultNotAvailable):
+        ak.ResultsClient(lean.plane).download_result_data(lean.session_id, deleted[0])
+
+
 def test_wave_level_execution_reports_the_per_task_statuses(cham):
     """A batch with failing members: every task gets the ProcessStatus (text included) that Execute gives it alone,
     and the good ones still run in the grouped launch."""
