@@ -219,7 +219,13 @@ ORC_API void orc_plgsy_tiles_lower(double *T, int Nb, int B, double bump, uint64
 }
 /* ... the leading Nb x Nb tiles of the matrix of order `order` >= Nb*B (entry (i,j) depends on the order through
  * the LCG position i + j*order): the leading block of a large factor is the factor of this leading block. */
+ORC_API void orc_plgsy_tiles_lower_at(double *T, int Nb, int B, double bump, uint64_t seed, int64_t order, int first);
 ORC_API void orc_plgsy_tiles_lower_of(double *T, int Nb, int B, double bump, uint64_t seed, int64_t order) {
+  orc_plgsy_tiles_lower_at(T, Nb, B, bump, seed, order, 0);
+}
+/* ... and the Nb x Nb tiles of the diagonal block that starts at tile (first, first) of that matrix (the trailing
+ * block: what the Schur-complement check of the tests takes A22 from). */
+ORC_API void orc_plgsy_tiles_lower_at(double *T, int Nb, int B, double bump, uint64_t seed, int64_t order, int first) {
   const uint64_t N = (uint64_t)order;
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int J = 0; J < Nb; ++J)
@@ -227,9 +233,9 @@ ORC_API void orc_plgsy_tiles_lower_of(double *T, int Nb, int B, double bump, uin
       if (I < J) continue;
       double *t = T + ((size_t)I + (size_t)J * Nb) * (size_t)B * B;
       for (int jj = 0; jj < B; ++jj) {
-        const uint64_t gj = (uint64_t)J * B + jj;
+        const uint64_t gj = ((uint64_t)first + J) * B + jj;
         const int i0 = (I == J) ? jj : 0; /* diagonal tile: from the diagonal down */
-        uint64_t ran = orc_lcg_jump(((uint64_t)I * B + i0) + gj * N, seed);
+        uint64_t ran = orc_lcg_jump((((uint64_t)first + I) * B + i0) + gj * N, seed);
         for (int ii = i0; ii < B; ++ii) {
           t[ii + (size_t)jj * B] = 0.5f - (double)ran * ORC_LCG_MUL;
           ran = ORC_LCG_A * ran + ORC_LCG_C;

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         L.orc_plgsy_tiles_lower.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64]
         L.orc_plgsy_tiles_lower_of.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int64]
         L.orc_plgsy_tiles_lower_of.restype = None
+        L.orc_plgsy_tiles_lower_at.argtypes = [_dpc, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int64, C.c_int]
+        L.orc_plgsy_tiles_lower_at.restype = None
         L.orc_dgemm_nt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int,
                                    C.c_double, _dp, C.c_int]
         L.orc_dsyrk_ln.argtypes = [C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_double, _dp, C.c_int]
@@ -142,6 +144,13 @@ def plgsy_tiles_lower(Nb: int, B: int, bump: float, seed: int, order: int | None
     tiles of the larger matrix of that order."""
     T = np.zeros(Nb * Nb * B * B, dtype=np.float64)
     lib().orc_plgsy_tiles_lower_of(T, Nb, B, float(bump), int(seed), int(order if order else Nb * B))
+    return T
+
+
+def plgsy_tiles_lower_at(Nb: int, B: int, bump: float, seed: int, order: int, first: int) -> np.ndarray:
+    """The Nb x Nb lower tiles of the diagonal block that starts at tile (first, first) of the order-`order` matrix."""
+    T = np.zeros(Nb * Nb * B * B, dtype=np.float64)
+    lib().orc_plgsy_tiles_lower_at(T, Nb, B, float(bump), int(seed), int(order), int(first))
     return T
 
 

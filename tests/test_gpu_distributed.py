@@ -101,6 +101,13 @@ def _worker_cabi(rank, world, port, N, B, q, bad, grid, dtype):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    # Should a rank ever sit in a transport call again (round 3: one 300 s hang of the 3 x 1 case, no stack kept), its
+    # Python stack goes to gpurun_out/ after 200 s -- before the parent's 300 s limit -- so that the blocked call is on file.
+    import faulthandler
+
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    _stk = open(os.path.join(ROOT, "gpurun_out", f"pxq_rank{rank}_of_{world}_stack.txt"), "w")
+    faulthandler.dump_traceback_later(200, file=_stk, exit=False)
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -134,6 +141,9 @@ def _worker_cabi(rank, world, port, N, B, q, bad, grid, dtype):
     q.put((rank, info, tiles, stats))
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    _stk.close()
+    os.unlink(_stk.name)  # (nothing to report)
 
 
 @pytest.mark.parametrize("world,bad,grid,dtype", [(2, None, None, "f64"), (4, None, None, "f64"), (4, 1300, None, "f64"),

@@ -169,11 +169,65 @@ def test_config2_matches_the_oracle_entry_by_entry(cham, orc, N, B):
     ch.CHAMELEON_Desc_Destroy(d)
 
 
-@pytest.mark.parametrize("N,B,dtype,lead,tol", [(32768, 512, "f64", 8192, 1e-12), (65536, 1024, "f64", 8192, 1e-12),
-                                                (131072, 1024, "f32", 4096, 1e-4)])
-def test_configs_3_to_5_leading_block_matches_the_oracle(cham, orc, N, B, dtype, lead, tol):
-    """BASELINE configs 3-5 at full size: the leading `lead` x `lead` block of the factor, entry by entry, against
-    the oracle's factorisation of the leading block of the same (order-N) matrix; the rest is covered by the residual."""
+def test_config3_matches_the_oracle_entry_by_entry(cham, orc):
+    """BASELINE config 3 (N=32768, tile=512) at full size: EVERY entry of the factor against the CPU oracle's wave DAG
+    on the same input (round 4; ~15 s of oracle on the GPU box's 16 cores, 8 GiB), max|dL| / max|L| <= 1e-12."""
+    ch = cham
+    N, B = 32768, 512
+    d = full_desc(ch, N, B)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    _compare_leading_tiles(ch, orc, d, N, B, N // B, 1e-12)
+    ch.CHAMELEON_Desc_Destroy(d)
+
+
+@pytest.mark.parametrize("N,B,dtype,trail,tol", [(65536, 1024, "f64", 8, 1e-12), (131072, 1024, "f32", 4, 1e-4)])
+def test_configs_4_and_5_trailing_tiles_match_the_oracle(cham, orc, N, B, dtype, trail, tol):
+    """BASELINE configs 4-5 at full size, the END of the run (the chain-bound, counter-linked waves): the trailing
+    `trail` x `trail` tiles of the factor are the Cholesky factor of the Schur complement  S = A22 - L21 L21^T.
+    L21 (the factor's last tile rows, downloaded) and A22 (the oracle's generator at that position of the order-N
+    matrix) give S on the host in fp64; the oracle factors it; entry by entry against the GPU's trailing tiles."""
+    ch = cham
+    dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
+    nt, n2 = N // B, trail * B
+    d = full_desc(ch, N, B, dt)
+    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    first = nt - trail
+    S = orc.tile_to_lapack(orc.plgsy_tiles_lower_at(trail, B, float(N), 42, N, first), n2, B)  # A22, lower tiles filled
+    S = np.asfortranarray(np.tril(S) + np.tril(S, -1).T)
+    if dtype == "f32":
+        S = S.astype(np.float32).astype(np.float64)  # (what the fp32 generator stored)
+    import torch  # (the checker's fp64 product: test infrastructure; 7.7 TFLOP at config 4 would take minutes on the host)
+
+    Sd = torch.from_numpy(S).cuda()
+    L21 = np.empty((n2, B), dtype=np.float64)
+    for J in range(first):  # one tile column of L21 at a time: S -= L21(:, J) L21(:, J)^T
+        for I in range(trail):
+            L21[I * B:(I + 1) * B, :] = d.download_tile(first + I, J)
+        Ld = torch.from_numpy(L21).cuda()
+        Sd -= Ld @ Ld.T
+    S = np.asfortranarray(Sd.cpu().numpy())
+    del Sd, Ld
+    Lref, info = orc.cholesky_lower(S, B)
+    assert info == 0
+    scale = np.abs(Lref).max()
+    worst = 0.0
+    for J in range(trail):
+        for I in range(J, trail):
+            got = d.download_tile(first + I, first + J).astype(np.float64)
+            ref = Lref[I * B:(I + 1) * B, J * B:(J + 1) * B]
+            diff = np.tril(got) - ref if I == J else got - ref
+            worst = max(worst, np.abs(diff).max() / scale)
+    assert worst <= tol, worst
+    ch.CHAMELEON_Desc_Destroy(d)
+
+
+@pytest.mark.parametrize("N,B,dtype,lead,tol", [(65536, 1024, "f64", 8192, 1e-12), (131072, 1024, "f32", 4096, 1e-4)])
+def test_configs_4_and_5_leading_block_matches_the_oracle(cham, orc, N, B, dtype, lead, tol):
+    """BASELINE configs 4-5 at full size: the leading `lead` x `lead` block of the factor, entry by entry, against
+    the oracle's factorisation of the leading block of the same (order-N) matrix; the trailing tiles by the test above,
+    the rest by the residual."""
     ch = cham
     dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
     d = full_desc(ch, N, B, dt)
