@@ -121,7 +121,7 @@ struct HipOps {
     if (g_ytab && reset_ytab) HIPRC(hipMemsetAsync(g_ytab, 0, YTAB_ENTRIES * sizeof(int), r.st[ST_MAIN]));
     // device-side edges of the panel chain (kernels.hip, sem_wait; cholmi_internal.h, SyrkPipe): 3 nbm + 1
     // counters per wave, the last one = workgroups of the last SYRK slice on tile (k+1,k+1)
-    sem_ok = r.d_sem && g.P * g.Q == 1 && (long)nt * sem_per_wave <= SEM_SLOTS;
+    sem_ok = r.d_sem && (long)nt * sem_per_wave <= SEM_SLOTS;
     if (sem_ok) HIPRC(hipMemsetAsync(r.d_sem, 0, (size_t)nt * sem_per_wave * 32 * sizeof(int), r.st[ST_MAIN]));
     return 0;
   }

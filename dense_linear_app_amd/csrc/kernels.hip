@@ -3072,9 +3072,10 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.diag = slot(s);
       ss.intile = slot(nbm + s);
       ss.intile_target = (flow ? 8 : 4) * nr;
-      ss.head = slot(2 * nbm + s);
+      ss.head = sy->c ? slot(2 * nbm + s) : nullptr;
       ss.fail = d_info;
       const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
+      if (!sy->c) continue;  // (a grid: the POTRF -> TRSM edge alone runs on counters, the next diagonal tile is elsewhere)
       const T *xs = tiles + (long)s * MACRO * mb;
       const long nslice = (long)(mb / 64) * (mb / 64 + 1) / 2;
       const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice);

@@ -338,6 +338,11 @@ struct Walker {
     int bnd = -1;
     bool prev_halves = false, prev_flow = false;
     const bool flags = !mr && o.counters();
+    // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
+    // owner of (k,k).  (The other -- last SYRK slice -> next POTRF -- never is: tile (k+1,k+1) belongs to another rank.)
+    // That edge runs on counters too (round 4): the TRSM steps are launched ahead and poll D[s] / I[s] instead of waiting
+    // for an event per step; everything that crosses a transport call stays an event.
+    const bool flags_local = mr && o.counters();
     const bool flow_run = (double)g.tiles_in(1, nt) * cal.t_tile < sw.pipe_fac * cal.t_panel;
     const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
     int wait_target = 0;
@@ -365,6 +370,7 @@ struct Walker {
       const bool plain_yield = (double)local_tiles * t_tile < sw.yfac * t_panel;
       const bool chain_bound = (double)local_tiles * t_tile < sw.pipe_fac * t_panel;
       const bool pipe = sw.syrk_pipe && flags && !paired && !last && o.pipe_ok() && plain_yield && chain_bound;
+      const bool pipe_local = sw.syrk_pipe && flags_local && !paired && o.pipe_ok() && plain_yield && chain_bound && own_diag && cntm > 0;
       // ... with its tile POTRF as a flow (kernels.hip: k_flow_factor) when the WHOLE factorisation is chain-bound (wave 0
       // already is): measured round 4, the form gains 14-17 % there (tile 512, N <= 4096) and nothing when only the last
       // waves of a larger matrix use it -- the wave that switches forms pays ~90 us, the rest gains ~40 us each
@@ -378,6 +384,11 @@ struct Walker {
       if (own_diag) {
         char *lkk = o.tile(k / P, k / Q);
         SyrkPipe sy;
+        if (pipe_local) {
+          sy.c = nullptr;  // (no SYRK slices: the next diagonal tile is another rank's)
+          sy.su = nullptr;
+          sy.sem = o.sem(k, 0, sem_per_wave);
+        }
         if (pipe) {
           // the tile's earlier writers: U2(k-1), whose range includes column k+1 (or, behind the paired
           // phase, the column launches of the last pair, which precede this on ST_U1)
@@ -395,7 +406,7 @@ struct Walker {
         // the head tile is this rank's first panel tile only when there is one process row
         const bool head_mine = !last && P == 1;
         WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine ? ev(k, E_HEAD) : -1,
-                    pipe ? &sy : nullptr, wait_sem, wait_target));
+                    pipe || pipe_local ? &sy : nullptr, wait_sem, wait_target));
         if (mr && P > 1 && !last) {
           WRC(o.rec(ev(k, E_LKK), ST_PANEL));
           WRC(diag_send(k, lkk, (const char *)o.winv(par)));
