@@ -750,6 +750,7 @@ int chol_init(int ncpu, int ngpu) {
     cholmi::g_poll_max_wgs = room < 0 ? 0 : (room < 48 ? room : 48);
   }
   if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
+  if (const char *e = getenv("CHOLMI_PERSIST")) cholmi::g_persist = atoi(e);
   if (const char *e = getenv("CHOLMI_FLOW")) cholmi::g_flow = atoi(e);
   if (const char *e = getenv("CHOLMI_FLOW_MAX_NBM")) cholmi::g_flow_max_nbm = std::min(8, atoi(e));
   if (const char *e = getenv("CHOLMI_FLOW_MIN_NBM")) cholmi::g_flow_min_nbm = std::max(2, atoi(e));

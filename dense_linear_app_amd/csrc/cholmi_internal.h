@@ -46,7 +46,7 @@ enum { ST_MAIN = 0, ST_PANEL, ST_TRSM, ST_U1, ST_CX, ST_PX, ST_COUNT };
 
 constexpr int SEM_SLOTS = 65536;   // device-side counters: 3 mb/128 + 1 per tile column (+ the flow's control block) ...
 constexpr int TILE_SEM_SETS = 8;   // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
-constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
+constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32 + 8) * 32;  // (+ 8: the per-XCD block counters of the persistent update launch)  // ... each on a 128-byte line of its own
 
 // device buffers that live as long as the context (receive buffers of the distributed walker)
 struct DevPool {
@@ -130,6 +130,7 @@ extern int g_trsm_small_max;
 extern int g_poll_max_wgs;
 // the flow form of a counter-linked wave's tile POTRF (kernels.hip: k_flow_factor): does it apply to tiles of nbm 128-blocks
 bool flow_applies(int nbm);
+extern int g_persist;
 extern int g_flow;
 extern int g_flow_min_nbm;
 extern int g_flow_max_nbm;
@@ -152,7 +153,8 @@ constexpr int YTAB_ENTRIES = 2048;
 // pan2 != null: the updates by two panels in one pass (C -= L L^T of `pan`, then of `pan2`)
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield = false, const PanelRef *pan2 = nullptr);
+                         int nb, const PanelRef &pan, bool yield = false, const PanelRef *pan2 = nullptr,
+                         int *persist_ctr = nullptr);  // persist_ctr: 8 x 32 ints of the stream's own; the launch deals its blocks itself
 
 // In-tile blocked POTRF of one mb x mb tile (device pointer, ld = mb).  Writes the
 // inverses of the MACRO x MACRO diagonal blocks of L to winv (mb/MACRO blocks of
@@ -192,6 +194,9 @@ struct SyrkPipe {
   hipStream_t sflow = nullptr;
   hipEvent_t ev_flow = nullptr;
   bool join_flow = false;  // the wave before was not in flow form
+  // column k+1 (not only its diagonal tile) is updated in K = 128 slices behind the panel's steps: the last slice's
+  // workgroups -- n (n + 1) / 2 + (ntiles - 1) n^2, n = mb / 64 -- are what `done` counts
+  bool col_slices = false;
 };
 inline int flow_ctl_lines(int nbm) { return nbm >= 2 && nbm <= 8 ? 1 + nbm + 2 * nbm * nbm : 0; }
 

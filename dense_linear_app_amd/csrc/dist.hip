@@ -150,7 +150,9 @@ struct HipOps {
   }
   int update(int, int, int jlo, int jhi, int what, const PanelRef &p1, const PanelRef *p2, bool yield, int st) {
     const ColRange c = col_range(d, jlo, jhi);
-    launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2);
+    // (the counters of the persistent form: behind the library's semaphores, used by ST_MAIN's launches only -- in order)
+    int *pc = (g_persist && st == ST_MAIN && r.d_sem) ? r.d_sem + (size_t)(SEM_SLOTS + TILE_SEM_SETS * 32) * 32 : nullptr;
+    launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2, pc);
     return launched();
   }
   // the streams have been joined into ST_MAIN and `ev_stop` recorded there

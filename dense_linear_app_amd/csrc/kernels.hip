@@ -585,8 +585,8 @@ struct BlockMap {
   int mi, mj;
 };
 __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, int na, int offb, int nb,
-                                                 int nbm, int blocks_a, int unit, BlockMap &out) {
-  int b = blockIdx.x;
+                                                 int nbm, int blocks_a, int unit, BlockMap &out, int b = -1) {
+  if (b < 0) b = blockIdx.x;
   if (na == 0 && nb == 1) {
     // one diagonal tile on its own (the SYRK that releases the next POTRF): nothing to share
     // through an L2, so its blocks go round-robin over all XCDs, one workgroup per CU
@@ -758,13 +758,12 @@ __device__ __forceinline__ void nt_kloop_w8(const T *__restrict__ A, int lda, co
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const int2 *__restrict__ list, int na,
-                                                             int offb, int nb, int blocks_a, PanelRef pan, int nbm,
-                                                             int unit, const int *ytab, PanelRef pan2, int npan) {
+__device__ __forceinline__ void trail_update_w8_block(const LocalMat &C, const int2 *__restrict__ list, int na, int offb,
+                                                      int nb, int blocks_a, const PanelRef &pan, int nbm, int unit,
+                                                      const int *ytab, const PanelRef &pan2, int npan, SmemP<T> &sm, int b) {
   using vec_t = typename Tr<T>::vec_t;
-  __shared__ SmemP<T> sm;
   BlockMap bm;
-  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
+  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm, b)) return;
   const int2 ij = bm.ij;
   const int mi = bm.mi, mj = bm.mj;
   const bool lower = (ij.x == ij.y) && mi == mj;
@@ -812,6 +811,36 @@ __global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const in
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const int2 *__restrict__ list, int na,
+                                                             int offb, int nb, int blocks_a, PanelRef pan, int nbm,
+                                                             int unit, const int *ytab, PanelRef pan2, int npan) {
+  __shared__ SmemP<T> sm;
+  trail_update_w8_block<T, MODE>(C, list, na, offb, nb, blocks_a, pan, nbm, unit, ytab, pan2, npan, sm, (int)blockIdx.x);
+}
+
+// The same update with a grid of the chip's resident slots (two workgroups per CU) whose workgroups deal themselves
+// the blocks: one counter per XCD (blockIdx & 7, as the static map assumes), a workgroup on XCD x takes the blocks
+// x, x + 8, x + 16, ... of the static numbering in turn, so the L2 locality of the unit scheme is kept.  Experiment of
+// round 4 (CHOLMI_PERSIST=1, the far launch only): what a launch of 4-16 rounds pays per round is dispatch, not work.
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 4) void k_trail_update_w8p(LocalMat C, const int2 *__restrict__ list, int na,
+                                                              int offb, int nb, int blocks_a, PanelRef pan, int nbm,
+                                                              int unit, const int *ytab, PanelRef pan2, int npan,
+                                                              int *ctr, int total) {
+  __shared__ SmemP<T> sm;
+  __shared__ int next_s;
+  const int x = blockIdx.x & 7;
+  for (;;) {
+    if (threadIdx.x == 0) next_s = __hip_atomic_fetch_add(ctr + 32 * x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int b = 8 * next_s + x;
+    __syncthreads();
+    if (b >= total) break;
+    trail_update_w8_block<T, MODE>(C, list, na, offb, nb, blocks_a, pan, nbm, unit, ytab, pan2, npan, sm, b);
   }
 }
 
@@ -945,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
                                                         int s, const T *__restrict__ winv, T alpha,
                                                         int *ytab, const int *wait_sem = nullptr,
                                                         int wait_target = 0, int *fail = nullptr,
-                                                        int *head_sem = nullptr) {
+                                                        int *head_sem = nullptr, int count_all = 0) {
   __shared__ SmemP<T> sm;
   sem_wait(wait_sem, wait_target, fail);
   GuestOnCu guest(ytab);
@@ -959,7 +988,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
   nt_kloop_paired<T, true>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
   nt_epilogue_paired<T>(Ap, mb, acc, alpha, T(0), false);
   guest.leave();
-  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: nr counts)
+  if (tix == 0 || count_all) sem_signal(head_sem);  // (the first tile's workgroups: nr counts -- or every tile's)
 }
 
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
@@ -1248,7 +1277,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int mb, int nbm, int r0, int s,
                                                         const T *__restrict__ winv, T alpha, int *ytab,
                                                         const int *wait_sem = nullptr, int wait_target = 0,
-                                                        int *fail = nullptr, int *head_sem = nullptr) {
+                                                        int *fail = nullptr, int *head_sem = nullptr, int count_all = 0) {
   __shared__ SmallImg<T, 32> ia;
   __shared__ SmallImg<T, MACRO> ib;
   sem_wait(wait_sem, wait_target, fail);
@@ -1288,7 +1317,7 @@ __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int
       for (int r = 0; r < 4; ++r)
         Ap[16 * a + lo + (long)(32 * w + 16 * b + Tr<T>::drow(lane, r)) * mb] = alpha * acc[a][b][r];
   guest.leave();
-  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: per_tile counts)
+  if (tix == 0 || count_all) sem_signal(head_sem);  // (the first tile's workgroups: per_tile counts -- or every tile's)
 }
 
 // C(r64, c64) -= A(r64, :) B(c64, :)^T over K columns, for the 64 x 64 blocks on or below the
@@ -2842,6 +2871,7 @@ int g_min_units = 128;  // a launch is dealt in units small enough to give at le
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
 int g_intile_fused_max = 256;  // ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3 (nr <= 10); beyond, resident pollers would queue for CU slots behind each other (CHOLMI_INTILE_FUSED_MAX)
 bool flow_applies(int nbm) { return g_flow && nbm >= g_flow_min_nbm && nbm <= g_flow_max_nbm; }
+int g_persist = 0;  // the far update launch (ST_MAIN) with a resident grid that deals itself its blocks (CHOLMI_PERSIST=1; experiment, round 4)
 int g_flow = 1;          // chain-bound waves: the tile POTRF as a flow of polling workgroups (CHOLMI_FLOW=0: diagonal-block + in-tile step launches)
 int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_MIN_NBM / _MAX_NBM): measured round 4, all waves
                                              // in flow form against none -- tile 512: +14 ... +17 % (N = 1536 ... 4096), +5 % (N = 5120, 6144); tile 256: -8 %
@@ -2857,7 +2887,7 @@ int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 
 
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield, const PanelRef *pan2) {
+                         int nb, const PanelRef &pan, bool yield, const PanelRef *pan2, int *persist_ctr) {
   if (na + nb <= 0) return;
   const int npan = pan2 ? 2 : 1;
   const PanelRef &p2 = pan2 ? *pan2 : pan;
@@ -2880,6 +2910,15 @@ void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, i
     if constexpr (sizeof(T) == 4)
       k_trail_update_w8f<<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
                                                    yield ? g_ytab : nullptr, p2, npan);
+    return;
+  }
+  if (g_variant >= 2 && sizeof(T) == 8 && persist_ctr && (blocks_a + blocks_b) > 1024) {
+    if constexpr (sizeof(T) == 8) {  // (the persistent form: launches of more than two rounds only)
+      (void)hipMemsetAsync(persist_ctr, 0, 8 * 32 * sizeof(int), s);
+      k_trail_update_w8p<T, 3><<<dim3(512), dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
+                                                               yield ? g_ytab : nullptr, p2, npan, persist_ctr,
+                                                               (int)(blocks_a + blocks_b));
+    }
     return;
   }
   if (g_variant >= 2 && sizeof(T) == 8) {
@@ -2916,6 +2955,7 @@ struct StepSems {
   const int *intile = nullptr;
   int intile_target = 0;
   int *head = nullptr;
+  bool head_all = false;  // `head` counts the solve's workgroups of EVERY tile (the column slices wait for the whole panel's step)
   int *fail = nullptr;
 };
 // (returns how many workgroups of the solve belong to the first tile: what `head` counts up to)
@@ -2926,7 +2966,7 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
   if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
     const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm * 4);
     k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab,
-                                                      p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
+                                                      p1 ? sm.diag : nullptr, 1, sm.fail, sm.head, sm.head_all ? 1 : 0);
     if (nc > 0) {
       const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, 4L * nbm * nc * ntiles);
       k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
@@ -2934,19 +2974,19 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
           lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz, nullptr,
           p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
     }
-    return 4 * nbm;
+    return 4 * nbm * (sm.head_all ? ntiles : 1);
   }
   // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
   // first update of blocks > 0
   const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm);
   k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab,
-                                                p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
+                                                p1 ? sm.diag : nullptr, 1, sm.fail, sm.head, sm.head_all ? 1 : 0);
   if (nc > 0) {
     const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, (long)ntiles * nbm * nc);
     k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab,
                                                         p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
   }
-  return nbm;
+  return nbm * (sm.head_all ? ntiles : 1);
 }
 
 // C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
@@ -3073,15 +3113,22 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.intile = slot(nbm + s);
       ss.intile_target = (flow ? 8 : 4) * nr;
       ss.head = sy->c ? slot(2 * nbm + s) : nullptr;
+      ss.head_all = sy->col_slices;
       ss.fail = d_info;
       const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
       if (!sy->c) continue;  // (a grid: the POTRF -> TRSM edge alone runs on counters, the next diagonal tile is elsewhere)
       const T *xs = tiles + (long)s * MACRO * mb;
-      const long nslice = (long)(mb / 64) * (mb / 64 + 1) / 2;
-      const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice);
-      k_small_update<T><<<dim3(mb / 64, mb / 64), 256, 0, sy->su>>>(
-          reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0, s == nbm - 1 ? slot(3 * nbm) : nullptr,
-          ps ? slot(2 * nbm + s) : nullptr, head_wgs, d_info);
+      const int n64 = mb / 64;
+      const long nslice = (long)n64 * (n64 + 1) / 2, noff = sy->col_slices ? (long)(nstep - 1) * n64 * n64 : 0;
+      int *done = s == nbm - 1 ? slot(3 * nbm) : nullptr;
+      const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice + noff);
+      k_small_update<T><<<dim3(n64, n64), 256, 0, sy->su>>>(reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0,
+                                                           0, done, ps ? slot(2 * nbm + s) : nullptr, head_wgs, d_info);
+      // column slices: the same K = 128 slice for every tile of column k+1 below its diagonal tile, so that when the
+      // panel's last step is done ONE slice is left of what the next wave's TRSM waits for, not a K = mb launch
+      if (noff > 0)
+        k_small_update<T><<<dim3(n64, n64, nstep - 1), 256, 0, sy->su>>>(reinterpret_cast<T *>(sy->c) + bsiz, mb, xs + bsiz, xs, mb,
+                                                                         MACRO, g_ytab, 1, bsiz, bsiz, done);
       continue;
     }
     // (recorded behind the in-tile update, not between the solve and the update: an event record
@@ -3226,7 +3273,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int, int,  \
-                                       int, const PanelRef &, bool, const PanelRef *);              \
+                                       int, const PanelRef &, bool, const PanelRef *, int *);       \
   template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int, int *);                \
   template void launch_diag_syrk<T>(hipStream_t, T *, const T *, int);                               \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \

@@ -92,7 +92,7 @@ struct WaveCalib {
 struct WaveSwitches {
   int pair_max_mb = 1024;
   double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0;
-  bool syrk_pipe = true, split_always = false, head_first = true;
+  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false;
   // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
   // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
   int pair_start = 1;
@@ -106,6 +106,7 @@ struct WaveSwitches {
     if (const char *e = getenv("CHOLMI_HALVES_MAX_ROUNDS")) halves_max_rounds = atof(e);
     if (const char *e = getenv("CHOLMI_SYRK_PIPE")) syrk_pipe = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_HEAD_FIRST")) head_first = atoi(e) != 0;
+    if (const char *e = getenv("CHOLMI_COL_SLICES")) col_slices = atoi(e) != 0;
     split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;
   }
 };
@@ -336,7 +337,7 @@ struct Walker {
     bool paired = false, cols_pending = false, had_pairs = false;
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
-    bool prev_halves = false, prev_flow = false;
+    bool prev_halves = false, prev_flow = false, prev_colsl = false;
     const bool flags = !mr && o.counters();
     // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
     // owner of (k,k).  (The other -- last SYRK slice -> next POTRF -- never is: tile (k+1,k+1) belongs to another rank.)
@@ -377,7 +378,11 @@ struct Walker {
       // (CHOLMI_FLOW_FACTOR = f > 0: instead, every wave whose update is shorter than f panel estimates)
       const bool flow = pipe && own_diag && cntm > 0 && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm) &&
                         (sw.flow_fac > 0 ? (double)local_tiles * t_tile < sw.flow_fac * t_panel : flow_run);
-      if (k > 0 && in_col) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
+      // ... and with column k+1 updated in K = 128 slices behind the panel's steps instead of by a launch that waits for
+      // the whole panel: the cycle TRSM(k) -> column-(k+1) update -> TRSM(k+1) shrinks to one slice.  The next wave's
+      // TRSM needs no event for it: its first step polls D[0], whose kernel has polled the last slice's counter.
+      const bool colsl = pipe && sw.col_slices && own_diag && cntm > 0;
+      if (k > 0 && in_col && !(prev_colsl && pipe)) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
       // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite its
       // set while TRSM(k) still reads the other
       const char *head = nullptr;
@@ -396,6 +401,7 @@ struct Walker {
           sy.c = o.tile((k + 1) / P, (k + 1) / Q);
           sy.su = (hipStream_t)o.stream(ST_U1);
           sy.sem = o.sem(k, 0, sem_per_wave);
+          sy.col_slices = colsl;
           if (flow) {
             sy.fc = o.sem(k, 3 * nbm + 1, sem_per_wave);
             sy.sflow = (hipStream_t)o.stream(ST_CX);
@@ -431,9 +437,10 @@ struct Walker {
       // reuse TRSM(k)'s workspace
       const bool by_flags = pipe;
       prev_flow = flow;
+      prev_colsl = colsl;
       if (flow) ++flow_waves;
       wait_sem = by_flags ? o.sem(k, 3 * nbm, sem_per_wave) : nullptr;
-      wait_target = (mb / 64) * (mb / 64 + 1) / 2;
+      wait_target = (mb / 64) * (mb / 64 + 1) / 2 + (colsl ? (cntm - 1) * (mb / 64) * (mb / 64) : 0);
       // TRSM(k) complete on this rank
       if (in_col) WRC(o.rec(ev(k, mr ? E_TRSM : E_PANEL), ST_TRSM));
       if (own_diag && !by_flags) {
@@ -592,10 +599,12 @@ struct Walker {
           WRC(o.diag_syrk(k, k + 1, ckk, head, ST_U1));
           WRC(o.rec(ev(k, E_U1D), ST_U1));
         }
-        WRC(o.wt(ST_U1, ev(k, E_PANEL)));
+        if (!colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
         if (halves && prof) WRC(o.rec(ev(k, E_PN0), ST_U1));
-        WRC(o.update(k, -1, k + 1, k + 2, 1, pk, nullptr, yield, ST_U1));
-        if (n_r1o > 0) ++timed;
+        if (!colsl) {  // (else: column k+1 went out in slices behind the panel's steps)
+          WRC(o.update(k, -1, k + 1, k + 2, 1, pk, nullptr, yield, ST_U1));
+          if (n_r1o > 0) ++timed;
+        }
         WRC(o.rec(ev(k, E_U1R), ST_U1));
         if (halves) {
           if (moved && prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));  // columns taken over from far(k-1)
@@ -636,7 +645,7 @@ struct Walker {
       // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
       // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
       upd_flops += (2.0 * n_r2o + n_r2d) * b3;
-      upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
+      if (!colsl) upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
     }
     if (open_bracket >= 0 && prof) {
       WRC(o.wt(ST_MAIN, fx(F_COLS)));
