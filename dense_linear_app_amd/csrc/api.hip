@@ -227,25 +227,32 @@ static inline ColRange col_range(const chol_desc *d, int jlo, int jhi) {
   return r;
 }
 
-// ---- sub-matrix views over a user buffer: the library works on a compact image of the view's tiles.
-// The user's matrix holds mb x mb tiles of bsiz elements (ld = mb); the image's tiles are mbi x mbi (mbi = mb
-// rounded up to 128, identity outside mb x mb): equal strides copy a whole tile column at once, a padded image
-// tile by tile with the two leading dimensions.
+// ---- sub-matrix views over a user buffer: the library works on a compact image of the view, tiled on its own.
+// The user's matrix holds whole mb x nb tiles of bsiz elements (ld = mb, tile (TI, TJ) at (TI + TJ lmt) bsiz); the
+// image's tiles are mbi x mbi (mb rounded up to 128, identity outside the matrix).  Entry (r, c) of the view is entry
+// (i + r, j + c) of the user's matrix: an image tile overlaps up to 2 x 2 user tiles (the view may start inside one --
+// v3_script_cholesky_x_arg_gpt.c:141-142, 186-212 accept any offset), each overlap one strided copy.
 int view_sync(chol_desc *d, bool in) {
-  const size_t ti = (size_t)d->bsizi * d->esize, tu = (size_t)d->bsiz * d->esize;
-  for (int J = 0; J < d->nt; ++J) {
-    char *user = reinterpret_cast<char *>(d->user_mat) + ((size_t)d->user_oi + (size_t)(J + d->user_oj) * d->user_lmt) * tu;
-    char *img = reinterpret_cast<char *>(d->mat) + (size_t)J * d->lmt * ti;
-    if (d->mbi == d->mb) {
-      HIPCHECK(hipMemcpy(in ? img : user, in ? user : img, (size_t)d->mt * ti, hipMemcpyDefault));
-      continue;
-    }
+  const size_t es = d->esize, ldu = (size_t)d->mb * es, ldi = (size_t)d->mbi * es;
+  const size_t ti = (size_t)d->bsizi * es, tu = (size_t)d->bsiz * es;
+  for (int J = 0; J < d->nt; ++J)
     for (int I = 0; I < d->mt; ++I) {
-      char *u = user + (size_t)I * tu, *m = img + (size_t)I * ti;
-      const size_t ldu = (size_t)d->mb * d->esize, ldi = (size_t)d->mbi * d->esize;
-      HIPCHECK(hipMemcpy2D(in ? m : u, in ? ldi : ldu, in ? u : m, in ? ldu : ldi, ldu, d->nb, hipMemcpyDefault));
+      char *img = reinterpret_cast<char *>(d->mat) + ((size_t)I + (size_t)J * d->lmt) * ti;
+      const int rows = std::min(d->mb, d->lm - I * d->mb), cols = std::min(d->nb, d->ln - J * d->nb);
+      for (int c0 = 0; c0 < cols;) {
+        const long C = (long)d->user_j + (long)J * d->nb + c0;  // user column
+        const int tj = (int)(C / d->nb), cj = (int)(C % d->nb), nc = std::min(cols - c0, d->nb - cj);
+        for (int r0 = 0; r0 < rows;) {
+          const long R = (long)d->user_i + (long)I * d->mb + r0;
+          const int tr = (int)(R / d->mb), ri = (int)(R % d->mb), nr = std::min(rows - r0, d->mb - ri);
+          char *u = reinterpret_cast<char *>(d->user_mat) + ((size_t)tr + (size_t)tj * d->user_lmt) * tu + ((size_t)ri + (size_t)cj * d->mb) * es;
+          char *m = img + ((size_t)r0 + (size_t)c0 * d->mbi) * es;
+          HIPCHECK(hipMemcpy2D(in ? m : u, in ? ldi : ldu, in ? u : m, in ? ldu : ldi, (size_t)nr * es, nc, hipMemcpyDefault));
+          r0 += nr;
+        }
+        c0 += nc;
+      }
     }
-  }
   return 0;
 }
 // One entry point's body between the refresh of its views' images and their write-back, all under the context
@@ -835,21 +842,22 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
     // straight through).  With library-owned storage nothing outside the view can ever be observed
     // through this descriptor -- Chameleon's generator, factorisation and layout conversions all work in
     // view coordinates (dplgsy: entry (r, c) of the view, order m) -- so the view IS an m x n matrix of
-    // its own: only the tiles it can address are allocated.  Tile-aligned offsets only (an unaligned
-    // view starts with a partial tile, which would change what tile (0,0) means to tile_upload / _download).
-    if (i % mb || j % nb) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views need tile-aligned offsets (i % mb == 0, j % nb == 0)");
+    // its own: only the tiles it can address are allocated (tile (0,0) of the descriptor = the first mb x nb entries of
+    // the VIEW, wherever it starts).
     if (p * q != 1) return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: sub-matrix views of distributed matrices are not supported");
     if (mat) {
-      // over a user buffer (v3's --mat user with offsets): the user's matrix is lm x ln in whole mb x nb tiles; the
-      // library keeps a compact image of the view's tiles and mirrors it around every operation (with_views)
-      if (lm % mb || ln % nb || m % mb || n % nb || mb != nb)
-        return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: a view over a user buffer needs whole square tiles (lm, ln, m, n multiples of mb = nb)");
+      // over a user buffer (v3's --mat user with offsets): the user's matrix is lm x ln in whole mb x nb tiles; the view
+      // may start anywhere in it and have any extent.  The library keeps a compact image of the view, tiled on its
+      // own, and mirrors it around every operation (with_views / view_sync)
+      if (lm % mb || ln % nb || mb != nb)
+        return fail(CHOL_ERR_NOT_SUPPORTED, "desc_create: a view over a user buffer needs a user matrix of whole square tiles (lm, ln multiples of mb = nb)");
       view_user = mat;
       view_lmt = lm / mb;
-      view_oi = i / mb;
-      view_oj = j / nb;
+      view_oi = i;
+      view_oj = j;
       mat = nullptr;
     }
+    // (library-owned storage: nothing outside the view can be observed, so an unaligned offset means nothing either)
     lm = m;
     ln = n;
     i = j = 0;
@@ -924,8 +932,8 @@ int chol_internal_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, 
   }
   d->user_mat = view_user;
   d->user_lmt = view_lmt;
-  d->user_oi = view_oi;
-  d->user_oj = view_oj;
+  d->user_i = view_oi;
+  d->user_j = view_oj;
   *desc = d;
   return 0;
 }

@@ -32,9 +32,10 @@ struct chol_desc {
   unsigned long long version = 0;
   // A sub-matrix view (i, j, m, n) over a USER buffer (tile-aligned offsets, whole tiles): `mat` is a library-owned
   // compact image of the view's tiles, refreshed from the user's tile matrix before every operation on this
-  // descriptor and written back after every operation that modifies it (api.hip: ViewSync).
+  // descriptor and written back after every operation that modifies it (api.hip: with_views).
   void *user_mat = nullptr;
-  int user_lmt = 0, user_oi = 0, user_oj = 0;  // the user's tile grid (rows) and the view's first tile in it
+  int user_lmt = 0;              // tile rows of the user's matrix
+  int user_i = 0, user_j = 0;    // the view's first ROW / COLUMN in it (any offset: a view may start inside a tile)
 };
 
 extern "C" int chol_internal_fail(int code, const char *msg);  // api.hip: sets chol_last_error, returns code

@@ -90,9 +90,9 @@ int chol_set_rank(int rank, int nranks);
 /* CHAMELEON_Desc_Create(&d, mat, dtype, mb, nb, bsiz, lm, ln, i, j, m, n, p, q)
  * W2:78 (1-tile wrap of a user buffer), V6:44 (mat = NULL: library-owned tile
  * storage) / CHAMELEON_Desc_Destroy W2:256, V6:90-91.
- * Sub-matrix views (i, j, m, n) != (0, 0, lm, ln): tile-aligned offsets only.  With mat = NULL the view is a
- * matrix of its own; over a user buffer (whole mb = nb tiles) the library mirrors the view's tiles through a
- * device image around every operation -- tiles outside the view are never touched. */
+ * Sub-matrix views (i, j, m, n) != (0, 0, lm, ln), any offset: with mat = NULL the view is a matrix of its
+ * own; over a user buffer (a matrix of whole mb = nb tiles) the library mirrors the view through a device
+ * image around every operation -- entries outside the view are never touched. */
 int chol_desc_create(chol_desc_t **desc, void *mat, int dtype, int mb, int nb, int bsiz, int lm,
                      int ln, int i, int j, int m, int n, int p, int q);
 int chol_desc_destroy(chol_desc_t **desc);

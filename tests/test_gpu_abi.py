@@ -37,7 +37,9 @@ def test_desc_create_argument_positions(cham):
     assert _desc(L, a, n=9)[0] == -12
     assert _desc(L, a, p=0)[0] == -13
     assert _desc(L, a, q=0)[0] == -14
-    assert _desc(L, a, i=2, m=6)[0] == -104  # sub-matrix view: valid Chameleon, not covered
+    rc, hv = _desc(L, a, i=2, m=6)  # a sub-matrix view that starts inside a tile: served (mirrored) since round 4
+    assert rc == 0 and L.chol_desc_destroy(C.byref(hv)) == 0
+    assert _desc(L, a, lm=12, ln=12, m=8, n=8)[0] == -104  # ... over a user matrix that is not made of whole tiles: not covered
     assert _desc(L, a, p=2)[0] == -104       # p*q must match the number of ranks
     assert b"chol_set_rank" in L.chol_last_error()
 
@@ -257,9 +259,14 @@ def test_submatrix_views_on_library_owned_descriptors(cham, orc):
     ch.CHAMELEON_dplgsy_Tile(616.0, ch.ChamLower, d2, 7)
     assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d2) == 0
     assert ch.residual_plgsy(d2, 616.0, 7) <= 1e-13
-    with pytest.raises(ch.CholmiError, match="tile-aligned"):
-        ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, 100, 0, m, m, 1, 1)
-    # over a user buffer a view needs whole tiles (test_sub_matrix_view_over_a_user_buffer covers the served case)
+    # an offset inside a tile (round 4): over library-owned storage nothing outside the view is observable, so the view is
+    # the same m x m matrix of its own wherever it starts
+    d3 = ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, 100, 37, m, m, 1, 1)
+    ch.CHAMELEON_dplgsy_Tile(float(m), ch.ChamUpperLower, d3, 42)
+    assert np.array_equal(d3.to_lapack(), A)
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d3) == 0
+    assert np.abs(np.tril(d3.to_lapack()) - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    # over a user buffer the USER's matrix must be made of whole tiles (test_sub_matrix_view_* cover the served cases)
     with pytest.raises(ch.CholmiError, match="user buffer"):
         ch.CHAMELEON_Desc_Create(np.zeros(2000 * 2000), ch.ChamRealDouble, mb, mb, mb * mb, 2000, 2000, i0, i0, m, m, 1, 1)
 
@@ -448,6 +455,43 @@ def test_sub_matrix_view_over_a_user_buffer(cham, orc, where, mb):
                 got = np.tril(got) if I - oi == J - oj else got
                 assert np.abs(got - ref).max() <= 1e-12 * np.abs(Lref).max(), (I, J)
     ch.CHAMELEON_Desc_Destroy(d)
-    # unaligned offsets stay refused
-    with pytest.raises(ch.CholmiError, match="tile-aligned"):
-        ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, 100, 0, m, m, 1, 1)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_sub_matrix_view_with_unaligned_offsets(cham, orc, where):
+    """v3_script_cholesky_x_arg_gpt.c:141-142, 186-212 accept any 0 <= i < lm: a view that starts INSIDE a tile of the user's
+    matrix and ends inside another (round 4).  The view's entries are mirrored through an image tiled on its own; every
+    entry of the user's buffer outside the view stays bit for bit what it was."""
+    import torch
+
+    ch = cham
+    mb, lt, i0, j0, m = 256, 5, 100, 100, 700  # rows / columns 100 .. 799 of a 1280 x 1280 matrix in 256-tiles
+    lm = lt * mb
+    rng = np.random.default_rng(11)
+    user = rng.standard_normal(lt * lt * mb * mb)
+
+    def to_lapack(flat):  # the user's tile layout -> an lm x lm array
+        t = flat.reshape(lt, lt, mb, mb)  # [J][I][jj][ii]
+        return t.transpose(1, 3, 0, 2).reshape(lm, lm)
+
+    A = orc.plgsy_matrix(m, float(m), 3)
+    buf = user.copy() if where == "host" else torch.from_numpy(user.copy()).cuda()
+    d = ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm, lm, i0, j0, m, m, 1, 1)
+    d.from_lapack(A)
+    mid = to_lapack(buf if where == "host" else buf.cpu().numpy())
+    assert np.array_equal(mid[i0:i0 + m, j0:j0 + m], A)  # the view's entries landed where the offsets say
+    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+    L = np.tril(d.to_lapack())
+    Lref = np.linalg.cholesky(A)
+    assert np.abs(L - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    after = to_lapack(buf if where == "host" else buf.cpu().numpy())
+    before = to_lapack(user)
+    outside = np.ones((lm, lm), dtype=bool)
+    outside[i0:i0 + m, j0:j0 + m] = False
+    assert np.array_equal(after[outside], before[outside])
+    assert np.abs(np.tril(after[i0:i0 + m, j0:j0 + m]) - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    assert np.array_equal(np.triu(after[i0:i0 + m, j0:j0 + m], 1), np.triu(A, 1))  # strict upper triangle of the view untouched
+    ch.CHAMELEON_Desc_Destroy(d)
+    # a user matrix that is not made of whole tiles stays refused
+    with pytest.raises(ch.CholmiError, match="whole square tiles"):
+        ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm - 10, lm - 10, 100, 0, m, m, 1, 1)
