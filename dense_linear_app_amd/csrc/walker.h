@@ -168,7 +168,7 @@ struct Walker {
   WaveCalib cal;
   WaveSwitches sw;
   enum { E_PANEL, E_U1D, E_U1R, E_U2, E_P0, E_P1, E_NEAR, E_PN0, E_PN1, E_TRSM, E_LKK, E_LKKR, E_HEAD, E_CXS, E_SU, E_PER_WAVE };
-  enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_COLS, F_CX, F_PX, F_FIXED };
+  enum { F_START, F_STOP, F_JOIN, F_WAVE, F_TRSM, F_U1END, F_COLS, F_CX, F_PX, F_FLOWJ, F_FIXED };
   enum { NBUF = 4 };
   // receive buffers: L(k,k) + block inverses and the head tile by wave parity, panel parts by wave mod NBUF
   char *lkk_buf[2] = {nullptr, nullptr}, *head_buf[2] = {nullptr, nullptr};
@@ -337,7 +337,7 @@ struct Walker {
     bool paired = false, cols_pending = false, had_pairs = false;
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
-    bool prev_halves = false, prev_flow = false, prev_colsl = false;
+    bool prev_halves = false, prev_flow = false, prev_colsl = false, flow_joined = false;
     const bool flags = !mr && o.counters();
     // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
     // owner of (k,k).  (The other -- last SYRK slice -> next POTRF -- never is: tile (k+1,k+1) belongs to another rank.)
@@ -406,7 +406,7 @@ struct Walker {
             sy.fc = o.sem(k, 3 * nbm + 1, sem_per_wave);
             sy.sflow = (hipStream_t)o.stream(ST_CX);
             sy.ev_flow = (hipEvent_t)o.flow_event();
-            sy.join_flow = !prev_flow;
+            sy.join_flow = !prev_flow && !flow_joined;
           }
         }
         // the head tile is this rank's first panel tile only when there is one process row
@@ -416,6 +416,15 @@ struct Walker {
         if (mr && P > 1 && !last) {
           WRC(o.rec(ev(k, E_LKK), ST_PANEL));
           WRC(diag_send(k, lkk, (const char *)o.winv(par)));
+        }
+        // the next wave switches to the flow form: its row-slab kernel's stream joins the POTRF stream's order NOW, a
+        // whole wave ahead, so that the event's wake-up (15-30 us) is not on the first flow wave's chain.  (Only behind
+        // a counter-linked wave: the row-slab kernel then polls the same counter as the POTRF's first kernel.)
+        if (pipe && !flow && !flow_joined && !mr && k + 2 < nt && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm) &&
+            (sw.flow_fac > 0 ? (double)g.tiles_in(k + 2, nt) * t_tile < sw.flow_fac * t_panel : flow_run)) {
+          WRC(o.rec(fx(F_FLOWJ), ST_PANEL));
+          WRC(o.wt(ST_CX, fx(F_FLOWJ)));
+          flow_joined = true;
         }
       } else if (in_col && cntm > 0) {
         WRC(diag_recv(k));
