@@ -762,6 +762,8 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_FLOW_MAX_NBM")) cholmi::g_flow_max_nbm = std::min(8, atoi(e));
   if (const char *e = getenv("CHOLMI_FLOW_MIN_NBM")) cholmi::g_flow_min_nbm = std::max(2, atoi(e));
   if (const char *e = getenv("CHOLMI_FLOW_FENCES")) cholmi::g_flow_fences = atoi(e);
+  if (const char *e = getenv("CHOLMI_FLOW_ROWS")) cholmi::g_flow_rows = atoi(e);
+  if (const char *e = getenv("CHOLMI_FLOW_PANEL_MAX")) cholmi::g_flow_panel_max = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED_MAX")) cholmi::g_intile_fused_max = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);

@@ -135,6 +135,9 @@ extern int g_persist;
 extern int g_flow;
 extern int g_flow_min_nbm;
 extern int g_flow_max_nbm;
+extern int g_flow_rows;  // 1: eager row slabs (k_flow_rows); 2: streaming (k_flow_rows2); 3: streaming, head tile included; 4: the whole panel (up to g_flow_panel_max tiles)
+extern int g_flow_panel_max;
+void launch_sem_set(hipStream_t s, int *sem);
 extern int g_flow_fences;
 extern int g_intile_fused;
 extern int g_intile_fused_max;
@@ -198,6 +201,10 @@ struct SyrkPipe {
   // column k+1 (not only its diagonal tile) is updated in K = 128 slices behind the panel's steps: the last slice's
   // workgroups -- n (n + 1) / 2 + (ntiles - 1) n^2, n = mb / 64 -- are what `done` counts
   bool col_slices = false;
+  // the flow's row-slab launch also solves the rows of the head tile L(k+1,k) (k_flow_rows2); head_ready: the counter
+  // a one-thread launch raises behind that tile's last writer, or null when the flow stream's order covers it
+  bool head_flow = false;
+  const int *head_ready = nullptr;
 };
 inline int flow_ctl_lines(int nbm) { return nbm >= 2 && nbm <= 8 ? 1 + nbm + 2 * nbm * nbm : 0; }
 
@@ -206,6 +213,9 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles,
                             hipEvent_t ev_head = nullptr, const SyrkPipe *sy = nullptr, const int *wait_sem = nullptr,
                             int wait_target = 0);
+
+template <typename T>
+void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz);
 
 // winv from an already factored tile
 template <typename T>

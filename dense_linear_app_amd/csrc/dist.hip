@@ -107,6 +107,10 @@ struct HipOps {
     if (!r.ev_flow) (void)hipEventCreateWithFlags(&r.ev_flow, hipEventDisableTiming);
     return r.ev_flow;
   }
+  int signal(int st, int *sem) {  // a counter raised in stream order: what a resident kernel of another stream polls
+    launch_sem_set(r.st[st], sem);
+    return launched();
+  }
   int launched() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
@@ -153,6 +157,12 @@ struct HipOps {
     // (the counters of the persistent form: behind the library's semaphores, used by ST_MAIN's launches only -- in order)
     int *pc = (g_persist && st == ST_MAIN && r.d_sem) ? r.d_sem + (size_t)(SEM_SLOTS + TILE_SEM_SETS * 32) * 32 : nullptr;
     launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2, pc);
+    return launched();
+  }
+  // one GPU: column k+1 below its diagonal tile, by panel k, in the latency form (kernels.hip: launch_col_update_small)
+  int update_col_small(int k, int st) {
+    launch_col_update_small<T>(r.st[st], (T *)tile(k + 2, k + 1), (const T *)tile(k + 2, k), (const T *)tile(k + 1, k), g.mb,
+                               g.nt - k - 2, (long)g.mb * g.mb);
     return launched();
   }
   // the streams have been joined into ST_MAIN and `ev_stop` recorded there
@@ -203,6 +213,8 @@ struct CbOps {
   int *sem(int, int, int) { return nullptr; }
   bool flow_ok() const { return false; }
   void *flow_event() { return nullptr; }
+  int signal(int, int *) { return 0; }
+  int update_col_small(int, int) { return 0; }
   int begin(int, int, int) { return 0; }
   int rec(int, int) { return 0; }
   int wt(int, int) { return 0; }

@@ -2624,6 +2624,229 @@ __global__ __launch_bounds__(256) void k_flow_rows(T *tile, int mb, int nbm, con
   if (blockIdx.x == 0) dbg_mark(dbg, 1, rb, t_in);
 }
 
+// ---- the streaming form of the row slabs (round 4, second version) -------------------------------------------
+// Every product of the tile POTRF's trailing update is taken ONE PANEL BEHIND the solve instead of after the step:
+// while the wave waits for panel p of L_s it already holds X_{p-1} of its rows, and the rows c' > s of the
+// diagonal tile publish their X(c', s) panel by panel, so  A(r, c') -= X_{p-1}(r) X_{p-1}(c')^T  needs nothing that
+// is not there -- its 32 operand loads fly beside the solve's, and when the step's last panel is solved one rank-16
+// product per block is left (the eager form left 8, 20-35 us of exposed load latency per block).  The blocks
+// (r, s+1), (r, s+2) live in accumulators for the whole tile POTRF -- at the end of step s the first becomes the
+// solve's right-hand side, nothing is written back and read again; a third block ahead (head rows of a 4-block
+// tile, step 0 only) lives in the wave's own 16 KiB of LDS.  Hence tiles of at most 4 blocks.
+// HEAD rows: the rows of the panel's first tile L(k+1,k) -- block row `nbm` of a column two tiles tall -- are
+// solved by this launch as well (mb / 64 more workgroups): they raise H[s], which the K = 128 slices of the SYRK
+// on tile (k+1,k+1) poll, ~3 us after the diagonal block's last panel instead of behind its 128 x 128 inverse,
+// the counter D[s] and a solve launch.  The tile's earlier writer (the update of column k by panel k-1, on ST_U1)
+// is a counter too (head_ready, raised by a one-thread launch behind it; null: stream order covers it).
+template <typename T>
+struct FlowRowsLds {
+  T acc[4][8 * 4 * 64];
+};
+// one round trip for up to four counters: lane i < 4 polls c[i] (null: nothing to wait for) for t[i], lane 4 the
+// abort word; false: aborted or gave up
+__device__ __forceinline__ bool flow_wait4(const int *c0, int t0, const int *c1, const int *c2, const int *c3, int *fc, int *info,
+                                           int fences) {
+  const int lane = threadIdx.x & 63;
+  const int *my = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : lane == 3 ? c3 : lane == 4 ? fc : nullptr;
+  const int tg = lane == 0 ? t0 : 8;
+  bool ok = false;
+  int i = 0;
+  for (; i < FLOW_SPIN; ++i) {
+    const int v = my ? __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const bool aborted = lane == 4 && v != 0, waiting = lane < 4 && my && v < tg;
+    if (__ballot(aborted) != 0ull) break;
+    if (__ballot(waiting) == 0ull) {
+      ok = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(FLOW_POLL_SLEEP);
+  }
+  if (i == FLOW_SPIN && lane == 0) {
+    atomicExch(info, 0x7ffffffe);
+    __hip_atomic_store(fc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (fences) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" ::: "memory");
+  return ok;
+}
+// panel p of block (c, s) of the diagonal tile as MFMA fragments: lf[j][r] = X[16 j + lo][16 p + drow(lane, r)]
+template <typename T>
+__device__ __forceinline__ void flow_xload(T (&lf)[8][4], const T *tile, int mb, int c, int s, int p, int lo, const size_t (&dcol)[4]) {
+  const T *Xc = tile + (size_t)(MACRO * c + lo) + (size_t)(MACRO * s + 16 * p) * mb;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lf[j][r] = load_sc1(Xc + 16 * j + dcol[r]);
+}
+template <typename T>
+__device__ __forceinline__ void flow_xmma(typename Tr<T>::acc_t (&acc)[8], const T (&lf)[8][4], const typename Tr<T>::acc_t &nx) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[j] = Tr<T>::mfma(lf[j][r], nx[r], acc[j]);
+}
+template <typename T>
+__device__ __forceinline__ void flow_xmma_lds(T *my, const T (&lf)[8][4], const typename Tr<T>::acc_t &nx) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    typename Tr<T>::acc_t t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = my[(j * 4 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t = Tr<T>::mfma(lf[j][r], nx[r], t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) my[(j * 4 + r) * 64 + lane] = t[r];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_flow_rows2(T *tile, T *head, long bsiz, int mb, int nbm, const T *winv, int *info, int *fc, int *ytab,
+                                                  const int *wait_sem, int wait_target, const int *head_ready, int *isem,
+                                                  int *hsem, int count_all, int fences, unsigned long long *dbg) {
+  using acc_t = typename Tr<T>::acc_t;
+  __shared__ FlowRowsLds<T> lds;
+  const unsigned long long t_in = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  sem_wait(wait_sem, wait_target, info);
+  GuestOnCu guest(ytab);
+  __builtin_amdgcn_s_setprio(2);
+  const int lane = threadIdx.x & 63, lo = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nin = (mb - MACRO) / 64;  // workgroups of the diagonal tile's own rows; then the head tile's
+  const bool is_head = (int)blockIdx.x >= nin;
+  const int hb = (int)blockIdx.x - nin, n64 = mb / 64;
+  const int ptile = is_head ? hb / n64 : 0;  // which tile of the panel (0: the head tile, whose steps H[s] counts)
+  const int R0 = is_head ? 64 * (hb % n64) + 16 * w : MACRO + 64 * (int)blockIdx.x + 16 * w;
+  const int rb = is_head ? nbm : R0 >> 7;  // block row: what the slab has to the left of its diagonal block
+  T *base = is_head ? head + (size_t)ptile * bsiz : tile;
+  size_t dcol[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dcol[r] = (size_t)Tr<T>::drow(lane, r) * mb;
+  T *mylds = lds.acc[w];
+  bool live = true;
+  if (is_head && head_ready) live = flow_wait(head_ready, 1, fc, info, 1);  // (an acquire: that launch stored normally)
+  acc_t a[8], acc0[8], acc1[8];
+  auto load_blk = [&](acc_t(&d)[8], int c) {
+    const T *B = base + (size_t)(R0 + lo) + (size_t)(MACRO * c) * mb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[j][r] = B[(size_t)(16 * j) * mb + dcol[r]];
+  };
+  if (live) {
+    load_blk(a, 0);
+    if (rb > 1) load_blk(acc0, 1);
+    if (rb > 2) load_blk(acc1, 2);
+    if (rb > 3) {
+      const T *B = base + (size_t)(R0 + lo) + (size_t)(MACRO * 3) * mb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mylds[(j * 4 + r) * 64 + lane] = B[(size_t)(16 * j) * mb + dcol[r]];
+    }
+  }
+  int signalled = 0;  // steps whose counter (I[s], or H[s] for head rows) this wave has raised
+  int *stepsem = is_head ? hsem : isem;
+  for (int s = 0; s < rb && live; ++s) {
+    const int nb = rb - 1 - s;                                        // blocks (rb, s+1 .. s+nb) take this step's products
+    T *Ab = base + (size_t)(R0 + lo) + (size_t)(MACRO * s) * mb;      // my rows of block (rb, s)
+    const T *Ws = winv + (size_t)s * MACRO * MACRO + lo;              // + (16 p) (1 + 128) + drow x 128
+    const T *Ls = tile + (size_t)s * MACRO * (mb + 1) + lo;           // diagonal block s: + 16 c + (16 p) mb + dcol
+    const int *fpan = fc + 32 * (1 + s);
+    const int *hq = fc + 32 * (1 + nbm + s);                          // + 32 nbm c': panels of X(c', s) published
+    int *hp = fc + 32 * (1 + nbm + rb * nbm + s);                     // mine (not for head rows: nobody reads them here)
+    const bool critical = !is_head && rb == s + 1;  // block row s+1: the next diagonal block waits for these panels one by one
+    const unsigned long long t_step = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    acc_t nprev;
+    static_for<0, 9>([&](auto P) {
+      constexpr int p = decltype(P)::value;
+      if (!live) return;
+      if constexpr (p == 8) {
+        if (nb == 0) return;
+      }
+      live = flow_wait4(p < 8 ? fpan : nullptr, p + 1, p > 0 && nb > 0 ? hq + 32 * nbm * (s + 1) + (p - 1) : nullptr,
+                        p > 0 && nb > 1 ? hq + 32 * nbm * (s + 2) + (p - 1) : nullptr,
+                        p > 0 && nb > 2 ? hq + 32 * nbm * (s + 3) + (p - 1) : nullptr, fc, info, fences);
+      if (!live) return;
+      T wd[4], lfL[8][4], lf0[8][4], lf1[8][4];
+      if constexpr (p < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wd[r] = load_sc1(Ws + (size_t)(16 * p) * (MACRO + 1) + (size_t)Tr<T>::drow(lane, r) * MACRO);
+#pragma unroll
+        for (int c = p + 1; c < 8; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lfL[c][r] = load_sc1(Ls + 16 * c + (size_t)(16 * p) * mb + dcol[r]);
+      }
+      if constexpr (p > 0) {
+        if (nb > 0) flow_xload<T>(lf0, tile, mb, s + 1, s, p - 1, lo, dcol);
+        if (nb > 1) flow_xload<T>(lf1, tile, mb, s + 2, s, p - 1, lo, dcol);
+      }
+      acc_t nx;
+      if constexpr (p < 8) {
+        acc_t x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x = Tr<T>::mfma(wd[r], a[p][r], x);  // X_p^T = W_p A_p^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_sc1(Ab + (size_t)(16 * p) * mb + dcol[r], x[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nx[r] = -x[r];
+#pragma unroll
+        for (int c = p + 1; c < 8; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[c] = Tr<T>::mfma(lfL[c][r], nx[r], a[c]);  // A_c -= X_p L(c,p)^T
+        if (critical || (is_head && p == 7)) {
+          flow_drain(fences);
+          if (!is_head && lane == 0) __hip_atomic_fetch_add(hp + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p == 7 && lane == 0 && (ptile == 0 || count_all)) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if constexpr (p > 0) {
+        if (nb > 0) flow_xmma<T>(acc0, lf0, nprev);
+        if (nb > 2) flow_xload<T>(lf0, tile, mb, s + 3, s, p - 1, lo, dcol);
+        if (nb > 1) flow_xmma<T>(acc1, lf1, nprev);
+        if (nb > 2) flow_xmma_lds<T>(mylds, lf0, nprev);
+      }
+      if constexpr (p < 8) {
+        if (!critical && !is_head) {
+          flow_drain(fences);
+          if (lane == 0) __hip_atomic_fetch_add(hp + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p == 7 && lane == 0) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p == 7) signalled = s + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nprev[r] = nx[r];
+      }
+    });
+    if (!live) break;
+    if (blockIdx.x == 0 || (int)blockIdx.x == nin - 1 || (int)blockIdx.x == nin || blockIdx.x == gridDim.x - 1) dbg_mark(dbg, (is_head ? 20 : 10) + s, rb, t_step);
+    // the block one to the right becomes the next step's right-hand side
+    if (nb > 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = acc0[j];
+    }
+    if (nb > 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc0[j] = acc1[j];
+    }
+    if (nb > 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[j][r] = mylds[(j * 4 + r) * 64 + lane];
+    }
+  }
+  // aborted: the counters the launches on the other streams poll still have to come
+  if (lane == 0 && (ptile == 0 || count_all))
+    for (int s = signalled; s < rb; ++s) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  guest.leave();
+  if (blockIdx.x == 0 || (int)blockIdx.x == nin) dbg_mark(dbg, is_head ? 2 : 1, rb, t_in);
+}
+
 // ------------------------------------------------------------------------------
 // plgsy: the matrix CHAMELEON_dplgsy_Tile generates (v6_test.c:46).  Chameleon's published
 // generator (coreblas core_dplgsy, from PLASMA) is a 64-bit LCG ran <- a*ran + 1 addressed by
@@ -2871,6 +3094,8 @@ int g_min_units = 128;  // a launch is dealt in units small enough to give at le
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
 int g_intile_fused_max = 256;  // ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3 (nr <= 10); beyond, resident pollers would queue for CU slots behind each other (CHOLMI_INTILE_FUSED_MAX)
 bool flow_applies(int nbm) { return g_flow && nbm >= g_flow_min_nbm && nbm <= g_flow_max_nbm; }
+int g_flow_rows = 1, g_flow_panel_max = 16;
+void launch_sem_set(hipStream_t s, int *sem) { k_sem_probe_set<<<1, 1, 0, s>>>(sem); }
 int g_persist = 0;  // the far update launch (ST_MAIN) with a resident grid that deals itself its blocks (CHOLMI_PERSIST=1; experiment, round 4)
 int g_flow = 1;          // chain-bound waves: the tile POTRF as a flow of polling workgroups (CHOLMI_FLOW=0: diagonal-block + in-tile step launches)
 int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_MIN_NBM / _MAX_NBM): measured round 4, all waves
@@ -2989,6 +3214,16 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
   return nbm * (sm.head_all ? ntiles : 1);
 }
 
+// Column k+1 below its diagonal tile in the LATENCY form: C_i -= A_i B^T, i = 0 .. ntiles-1 (tiles bsiz apart, B the head
+// tile), in 64 x 64 blocks -- (mb / 64)^2 workgroups per tile instead of the update kernel's (mb / 128)^2 or fewer.  A
+// third of that kernel's rate per CU, but a chain-bound wave has the CUs to spare and waits for exactly this launch.
+template <typename T>
+void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz) {
+  if (ntiles > 0) k_small_update<T><<<dim3(mb / 64, mb / 64, ntiles), 256, 0, s>>>(C, mb, A, B, mb, mb, g_ytab, 1, bsiz, bsiz);
+}
+template void launch_col_update_small<double>(hipStream_t, double *, const double *, const double *, int, int, long);
+template void launch_col_update_small<float>(hipStream_t, float *, const float *, const float *, int, int, long);
+
 // C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
 template <typename T>
 void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb) {
@@ -3065,6 +3300,11 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
   // the tile POTRF as a flow (k_flow_factor / k_flow_rows): the diagonal-block steps raise D[s] as before, the
   // row-slab waves I[s] (8 (nbm - 1 - s) of them instead of the 4 (nbm - 1 - s) workgroups of the in-tile solve)
   const bool flow = pipe && sy->fc && sy->sflow && flow_applies(nbm);
+  const bool rows2 = flow && g_flow_rows >= 2 && nbm <= 4;  // (the streaming row slabs keep two blocks ahead in registers)
+  // ... which then take the head tile's rows along: TRSM step s covers the panel's other tiles only, H[s] counts waves
+  const bool head_flow = rows2 && g_flow_rows >= 3 && sy->head_flow && sy->c && nstep >= 1;
+  // ... and the panel's other tiles, while there are few of them (g_flow_rows >= 4): no TRSM launch is left
+  const int nflow = !head_flow ? 0 : g_flow_rows >= 4 && nstep <= g_flow_panel_max ? nstep : 1;
   if (flow) {
     if (sy->join_flow && sy->ev_flow) {  // first flow-form wave: the flow stream joins the POTRF stream's order once (without it the
                                          // row-slab kernel would sit on the chip, polling, from the moment the host issues it)
@@ -3073,8 +3313,13 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
     }
     k_flow_factor<T><<<nbm, 256, 0, sp>>>(lkk, mb, nbm, winv, d_info, info_base, sy->fc, g_ytab, wait_sem, wait_target,
                                           slot(0), g_flow_fences, g_dbg);
-    k_flow_rows<T><<<(mb - MACRO) / 64, 256, 0, sy->sflow>>>(lkk, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem,
-                                                           wait_target, slot(nbm), g_flow_fences, g_dbg);
+    if (rows2)
+      k_flow_rows2<T><<<(mb - MACRO) / 64 + nflow * (mb / 64), 256, 0, sy->sflow>>>(
+          lkk, tiles, bsiz, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem, wait_target, head_flow ? sy->head_ready : nullptr, slot(nbm),
+          slot(2 * nbm), sy->col_slices ? 1 : 0, g_flow_fences, g_dbg);
+    else
+      k_flow_rows<T><<<(mb - MACRO) / 64, 256, 0, sy->sflow>>>(lkk, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem, wait_target,
+                                                             slot(nbm), g_flow_fences, g_dbg);
   }
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
@@ -3115,7 +3360,16 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.head = sy->c ? slot(2 * nbm + s) : nullptr;
       ss.head_all = sy->col_slices;
       ss.fail = d_info;
-      const int head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
+      int head_wgs = mb / 16;
+      if (head_flow) {
+        // H[s]: the head tile's waves -- or, with column slices, every wave and workgroup that solves a tile of the panel
+        if (!sy->col_slices) ss.head = nullptr;
+        int more = 0;
+        if (nstep > nflow) more = trsm_step<T>(st, tiles + nflow * bsiz, bsiz, nstep - nflow, lkk, winv, mb, s, T(1), ss);
+        if (sy->col_slices) head_wgs = nflow * (mb / 16) + more;
+      } else {
+        head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
+      }
       if (!sy->c) continue;  // (a grid: the POTRF -> TRSM edge alone runs on counters, the next diagonal tile is elsewhere)
       const T *xs = tiles + (long)s * MACRO * mb;
       const int n64 = mb / 64;

@@ -91,8 +91,9 @@ struct WaveCalib {
 // switches of the schedule (environment, read once; CHOLMI_* names in DESIGN.md section 4)
 struct WaveSwitches {
   int pair_max_mb = 1024;
-  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0;
-  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false;
+  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0, near_fac = 0.7;
+  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false, pipe_near = true;
+  int u1_small_max = 8;  // counter-linked waves: column k+1 in the latency form while it has at most this many tiles below the diagonal (CHOLMI_U1_SMALL)
   // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
   // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
   int pair_start = 1;
@@ -107,6 +108,9 @@ struct WaveSwitches {
     if (const char *e = getenv("CHOLMI_SYRK_PIPE")) syrk_pipe = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_HEAD_FIRST")) head_first = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_COL_SLICES")) col_slices = atoi(e) != 0;
+    if (const char *e = getenv("CHOLMI_PIPE_NEAR")) pipe_near = atoi(e) != 0;
+    if (const char *e = getenv("CHOLMI_NEAR_FACTOR")) near_fac = atof(e);
+    if (const char *e = getenv("CHOLMI_U1_SMALL")) u1_small_max = atoi(e);
     split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;
   }
 };
@@ -329,7 +333,8 @@ struct Walker {
     const auto t_host0 = std::chrono::steady_clock::now();
     const int nt = g.nt, mb = g.mb, nbm = g.nbm, P = g.P, Q = g.Q;
     const bool mr = multi();
-    const int sem_per_wave = 3 * nbm + 1 + flow_ctl_lines(nbm);  // SyrkPipe's counters, then the flow's control block
+    const int sem_per_wave = 3 * nbm + 2 + flow_ctl_lines(nbm);  // SyrkPipe's counters, the flow's control block, `head tile ready`
+    const int sem_head_ready = 3 * nbm + 1 + flow_ctl_lines(nbm);
     WRC(o.begin(E_PER_WAVE * nt + F_FIXED + nbm + 1, nt, sem_per_wave));
     const int ev_steps = fx(F_FIXED);
     WRC(o.rec(fx(F_START), ST_MAIN));
@@ -338,6 +343,7 @@ struct Walker {
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
     bool prev_halves = false, prev_flow = false, prev_colsl = false, flow_joined = false;
+    bool head_sig_next = false;  // the last wave raised this wave's `head tile ready` counter behind its column update
     const bool flags = !mr && o.counters();
     // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
     // owner of (k,k).  (The other -- last SYRK slice -> next POTRF -- never is: tile (k+1,k+1) belongs to another rank.)
@@ -352,6 +358,9 @@ struct Walker {
     const bool prof = o.profiling();
     for (int k = 0; k < nt; ++k) {
       const int dr = k % P, dc = k % Q, par = k & 1;
+      const bool head_sig = head_sig_next;
+      head_sig_next = false;
+      bool head_flow = false;  // the flow's row-slab launch solves the head tile L(k+1,k) too
       const bool in_col = g.pc == dc, own_diag = in_col && g.pr == dr, last = k + 1 >= nt;
       int il0m = 0, cntm = 0;
       g.part(k, g.pr, &il0m, &cntm);
@@ -397,7 +406,8 @@ struct Walker {
         if (pipe) {
           // the tile's earlier writers: U2(k-1), whose range includes column k+1 (or, behind the paired
           // phase, the column launches of the last pair, which precede this on ST_U1)
-          if (k > 0) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));
+          // (... or near(k-1): column k+1 alone, on this very stream)
+          if (k > 0 && !prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));
           sy.c = o.tile((k + 1) / P, (k + 1) / Q);
           sy.su = (hipStream_t)o.stream(ST_U1);
           sy.sem = o.sem(k, 0, sem_per_wave);
@@ -407,12 +417,18 @@ struct Walker {
             sy.sflow = (hipStream_t)o.stream(ST_CX);
             sy.ev_flow = (hipEvent_t)o.flow_event();
             sy.join_flow = !prev_flow && !flow_joined;
+            // the head tile's rows in the same launch: its last writer is stream order at wave 0, else the column
+            // update of the last wave, which then raised a counter behind itself
+            head_flow = g_flow_rows >= 3 && nbm <= 4 && !last && P == 1 && (k == 0 || head_sig);
+            sy.head_flow = head_flow;
+            sy.head_ready = k == 0 ? nullptr : o.sem(k, sem_head_ready, sem_per_wave);
           }
         }
         // the head tile is this rank's first panel tile only when there is one process row
         const bool head_mine = !last && P == 1;
-        WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine ? ev(k, E_HEAD) : -1,
+        WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine && !head_flow ? ev(k, E_HEAD) : -1,
                     pipe || pipe_local ? &sy : nullptr, wait_sem, wait_target));
+        if (head_flow) WRC(o.rec(ev(k, E_HEAD), ST_CX));  // (the head tile is complete when the row-slab launch is)
         if (mr && P > 1 && !last) {
           WRC(o.rec(ev(k, E_LKK), ST_PANEL));
           WRC(diag_send(k, lkk, (const char *)o.winv(par)));
@@ -583,8 +599,17 @@ struct Walker {
       const int tiles2 = n_r2o + n_r2d;
       bool halves = sw.halves_max_rounds > 0 && !pipe && split && nt - 1 - k >= 6 &&
                     (double)tiles2 * nbm * nbm / 512.0 < sw.halves_max_rounds;
+      // Counter-linked waves (CHOLMI_PIPE_NEAR): the near half is column k+2 alone, every wave.  The SYRK slices of the
+      // NEXT wave (tile (k+2,k+2), on ST_U1) then follow near(k) in stream order instead of waiting for the whole far
+      // update of this wave, which started only when this panel was complete: the chain looks two columns ahead.
+      const bool near1 = pipe && sw.pipe_near && split && k + 3 < nt && (double)local_tiles * t_tile < sw.near_fac * t_panel;
       bool moved = false;
-      if (halves) {
+      if (near1) {
+        halves = true;
+        if (prev_halves && bnd > k + 3) WRC(o.wt(ST_MAIN, ev(k - 1, E_NEAR)));  // (from the wider halves of the waves before)
+        bnd = k + 3;
+        moved = true;
+      } else if (halves) {
         if (!prev_halves || bnd <= k + 2 || g.tiles_in(k + 2, bnd) * 10 < tiles2 * 3) {
           int b = k + 3;
           while (b < nt - 1 && g.tiles_in(k + 2, b) * 2 < tiles2) ++b;
@@ -600,7 +625,9 @@ struct Walker {
       // column k+1 was in U2(k-1)'s range -- or in near(k-1)'s, which precedes this on ST_U1
       if (k > 0 && !prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));
       WRC(o.wt(ST_MAIN, ev(k, E_PANEL)));
+      if (head_flow) WRC(o.wt(ST_MAIN, ev(k, E_HEAD)));
       int timed = 0;  // k_trail_update launches inside this wave's profiling bracket
+      const bool u1s = pipe && !colsl && !mr && n_r1o > 0 && n_r1o <= sw.u1_small_max;
       if (split) {
         // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
         // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
@@ -609,13 +636,22 @@ struct Walker {
           WRC(o.rec(ev(k, E_U1D), ST_U1));
         }
         if (!colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
+        if (head_flow) WRC(o.wt(ST_U1, ev(k, E_HEAD)));
         if (halves && prof) WRC(o.rec(ev(k, E_PN0), ST_U1));
-        if (!colsl) {  // (else: column k+1 went out in slices behind the panel's steps)
+        if (u1s) {
+          WRC(o.update_col_small(k, ST_U1));
+        } else if (!colsl) {  // (else: column k+1 went out in slices behind the panel's steps)
           WRC(o.update(k, -1, k + 1, k + 2, 1, pk, nullptr, yield, ST_U1));
           if (n_r1o > 0) ++timed;
         }
         WRC(o.rec(ev(k, E_U1R), ST_U1));
+        if (pipe && g_flow_rows >= 3 && nbm <= 4 && k + 2 < nt && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm)) {
+          // the next wave's head tile L(k+2,k+1) has its last update: a counter, for the row-slab launch that may solve it
+          WRC(o.signal(ST_U1, o.sem(k + 1, sem_head_ready, sem_per_wave)));
+          head_sig_next = true;
+        }
         if (halves) {
+          if (colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));  // (the slices polled; this launch needs the whole panel)
           if (moved && prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));  // columns taken over from far(k-1)
           WRC(o.update(k, -1, k + 2, bnd, 3, pk, nullptr, yield, ST_U1));
           if (g.tiles_in(k + 2, bnd) > 0) ++timed;
@@ -654,7 +690,7 @@ struct Walker {
       // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
       // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
       upd_flops += (2.0 * n_r2o + n_r2d) * b3;
-      if (!colsl) upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
+      if (!colsl && !u1s) upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
     }
     if (open_bracket >= 0 && prof) {
       WRC(o.wt(ST_MAIN, fx(F_COLS)));

@@ -24,7 +24,9 @@ names = {1: "rows_i", 2: "rows_p", 3: "E_i", 4: "E_p", 5: "slice_d", 6: "slice_o
 ev = []
 for r in a:
     if 0 < r[2] < 100:
-        ev.append((r[0], r[1], f"{names.get(int(r[2]), '?')}({int(r[3])})"))
+        t = int(r[2])
+        nm = names.get(t) or (f"rows step {t - 10} block row" if t < 20 else f"head step {t - 20} block row")
+        ev.append((r[0], r[1], f"{nm}({int(r[3])})"))
     else:  # a diagonal-block workgroup: entry, end, factor start
         ev.append((r[0], r[1], f"F  factor_start=+{(r[2] - r[0]) / 100:.1f} A={r[3] / 100:.1f} B={r[4] / 100:.1f}"))
 ev.sort()

@@ -9,7 +9,7 @@ import sys
 f = sys.argv[1]
 rows = []
 for r in csv.DictReader(open(f)):
-    n = r["Kernel_Name"].split("(")[0].replace("void cholmi::", "").strip()
+    n = r["Kernel_Name"].split("(")[0].replace("void cholmi::", "").replace("cholmi::", "").strip()
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Queue_Id", "?"), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
                  int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)))
 rows.sort()
