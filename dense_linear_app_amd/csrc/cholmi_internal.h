@@ -205,6 +205,10 @@ struct SyrkPipe {
   // a one-thread launch raises behind that tile's last writer, or null when the flow stream's order covers it
   bool head_flow = false;
   const int *head_ready = nullptr;
+  // H[nbm-1] counts the last step's solves of EVERY panel tile: "panel complete" as a counter (what a gate ahead of the
+  // column-(k+1) launch polls instead of waiting for an event); the launcher reports what it counts up to
+  bool panel_done_all = false;
+  mutable int panel_target = 0;
 };
 inline int flow_ctl_lines(int nbm) { return nbm >= 2 && nbm <= 8 ? 1 + nbm + 2 * nbm * nbm : 0; }
 
@@ -215,7 +219,8 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                             int wait_target = 0);
 
 template <typename T>
-void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz);
+void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz, int *done);
+void launch_sem_gate(hipStream_t s, const int *sem, int target, int *fail);
 
 // winv from an already factored tile
 template <typename T>

@@ -160,9 +160,13 @@ struct HipOps {
     return launched();
   }
   // one GPU: column k+1 below its diagonal tile, by panel k, in the latency form (kernels.hip: launch_col_update_small)
-  int update_col_small(int k, int st) {
+  int update_col_small(int k, int st, int *done) {
     launch_col_update_small<T>(r.st[st], (T *)tile(k + 2, k + 1), (const T *)tile(k + 2, k), (const T *)tile(k + 1, k), g.mb,
-                               g.nt - k - 2, (long)g.mb * g.mb);
+                               g.nt - k - 2, (long)g.mb * g.mb, done);
+    return launched();
+  }
+  int gate(int st, const int *sem, int target) {  // the stream goes on when the counter has reached its target
+    launch_sem_gate(r.st[st], sem, target, r.d_info);
     return launched();
   }
   // the streams have been joined into ST_MAIN and `ev_stop` recorded there
@@ -214,7 +218,8 @@ struct CbOps {
   bool flow_ok() const { return false; }
   void *flow_event() { return nullptr; }
   int signal(int, int *) { return 0; }
-  int update_col_small(int, int) { return 0; }
+  int update_col_small(int, int, int *) { return 0; }
+  int gate(int, const int *, int) { return 0; }
   int begin(int, int, int) { return 0; }
   int rec(int, int) { return 0; }
   int wt(int, int) { return 0; }

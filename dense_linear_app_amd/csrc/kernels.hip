@@ -3096,6 +3096,7 @@ int g_intile_fused_max = 256;  // ... while the step has at most this many polli
 bool flow_applies(int nbm) { return g_flow && nbm >= g_flow_min_nbm && nbm <= g_flow_max_nbm; }
 int g_flow_rows = 1, g_flow_panel_max = 16;
 void launch_sem_set(hipStream_t s, int *sem) { k_sem_probe_set<<<1, 1, 0, s>>>(sem); }
+void launch_sem_gate(hipStream_t s, const int *sem, int target, int *fail) { k_sem_gate<<<1, 64, 0, s>>>(sem, target, fail); }
 int g_persist = 0;  // the far update launch (ST_MAIN) with a resident grid that deals itself its blocks (CHOLMI_PERSIST=1; experiment, round 4)
 int g_flow = 1;          // chain-bound waves: the tile POTRF as a flow of polling workgroups (CHOLMI_FLOW=0: diagonal-block + in-tile step launches)
 int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_MIN_NBM / _MAX_NBM): measured round 4, all waves
@@ -3218,11 +3219,12 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
 // tile), in 64 x 64 blocks -- (mb / 64)^2 workgroups per tile instead of the update kernel's (mb / 128)^2 or fewer.  A
 // third of that kernel's rate per CU, but a chain-bound wave has the CUs to spare and waits for exactly this launch.
 template <typename T>
-void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz) {
-  if (ntiles > 0) k_small_update<T><<<dim3(mb / 64, mb / 64, ntiles), 256, 0, s>>>(C, mb, A, B, mb, mb, g_ytab, 1, bsiz, bsiz);
+void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz, int *done) {
+  // (done, may be null: raised once by each of the (mb / 64)^2 ntiles workgroups)
+  if (ntiles > 0) k_small_update<T><<<dim3(mb / 64, mb / 64, ntiles), 256, 0, s>>>(C, mb, A, B, mb, mb, g_ytab, 1, bsiz, bsiz, done);
 }
-template void launch_col_update_small<double>(hipStream_t, double *, const double *, const double *, int, int, long);
-template void launch_col_update_small<float>(hipStream_t, float *, const float *, const float *, int, int, long);
+template void launch_col_update_small<double>(hipStream_t, double *, const double *, const double *, int, int, long, int *);
+template void launch_col_update_small<float>(hipStream_t, float *, const float *, const float *, int, int, long, int *);
 
 // C(mb x mb, lower) -= A A^T with A one mb x mb tile: the SYRK that releases the next POTRF
 template <typename T>
@@ -3358,7 +3360,7 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.intile = slot(nbm + s);
       ss.intile_target = (flow ? 8 : 4) * nr;
       ss.head = sy->c ? slot(2 * nbm + s) : nullptr;
-      ss.head_all = sy->col_slices;
+      ss.head_all = sy->col_slices || (sy->panel_done_all && s == nbm - 1 && !head_flow && sy->c);
       ss.fail = d_info;
       int head_wgs = mb / 16;
       if (head_flow) {
@@ -3369,6 +3371,7 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
         if (sy->col_slices) head_wgs = nflow * (mb / 16) + more;
       } else {
         head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
+        if (s == nbm - 1) sy->panel_target = ss.head_all ? head_wgs : 0;
       }
       if (!sy->c) continue;  // (a grid: the POTRF -> TRSM edge alone runs on counters, the next diagonal tile is elsewhere)
       const T *xs = tiles + (long)s * MACRO * mb;

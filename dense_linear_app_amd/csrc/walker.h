@@ -92,7 +92,7 @@ struct WaveCalib {
 struct WaveSwitches {
   int pair_max_mb = 1024;
   double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0, near_fac = 0.7;
-  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false, pipe_near = true;
+  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false, pipe_near = true, u1_counters = false;
   int u1_small_max = 8;  // counter-linked waves: column k+1 in the latency form while it has at most this many tiles below the diagonal (CHOLMI_U1_SMALL)
   // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
   // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
@@ -111,6 +111,7 @@ struct WaveSwitches {
     if (const char *e = getenv("CHOLMI_PIPE_NEAR")) pipe_near = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_NEAR_FACTOR")) near_fac = atof(e);
     if (const char *e = getenv("CHOLMI_U1_SMALL")) u1_small_max = atoi(e);
+    if (const char *e = getenv("CHOLMI_U1_COUNTERS")) u1_counters = atoi(e) != 0;
     split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;
   }
 };
@@ -333,8 +334,8 @@ struct Walker {
     const auto t_host0 = std::chrono::steady_clock::now();
     const int nt = g.nt, mb = g.mb, nbm = g.nbm, P = g.P, Q = g.Q;
     const bool mr = multi();
-    const int sem_per_wave = 3 * nbm + 2 + flow_ctl_lines(nbm);  // SyrkPipe's counters, the flow's control block, `head tile ready`
-    const int sem_head_ready = 3 * nbm + 1 + flow_ctl_lines(nbm);
+    const int sem_per_wave = 3 * nbm + 3 + flow_ctl_lines(nbm);  // SyrkPipe's counters, the flow's control block, `head tile ready`, `column k+1 updated`
+    const int sem_head_ready = 3 * nbm + 1 + flow_ctl_lines(nbm), sem_u1_done = sem_head_ready + 1;
     WRC(o.begin(E_PER_WAVE * nt + F_FIXED + nbm + 1, nt, sem_per_wave));
     const int ev_steps = fx(F_FIXED);
     WRC(o.rec(fx(F_START), ST_MAIN));
@@ -343,6 +344,7 @@ struct Walker {
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
     bool prev_halves = false, prev_flow = false, prev_colsl = false, flow_joined = false;
+    int u1_target_prev = 0;  // > 0: the last wave's column-(k+1) launch raises a counter, up to this
     bool head_sig_next = false;  // the last wave raised this wave's `head tile ready` counter behind its column update
     const bool flags = !mr && o.counters();
     // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
@@ -361,6 +363,9 @@ struct Walker {
       const bool head_sig = head_sig_next;
       head_sig_next = false;
       bool head_flow = false;  // the flow's row-slab launch solves the head tile L(k+1,k) too
+      const int u1_target_last = u1_target_prev;
+      u1_target_prev = 0;
+      int panel_target = 0;  // > 0: H[nbm-1] of this wave counts up to this when the panel is complete
       const bool in_col = g.pc == dc, own_diag = in_col && g.pr == dr, last = k + 1 >= nt;
       int il0m = 0, cntm = 0;
       g.part(k, g.pr, &il0m, &cntm);
@@ -391,7 +396,10 @@ struct Walker {
       // the whole panel: the cycle TRSM(k) -> column-(k+1) update -> TRSM(k+1) shrinks to one slice.  The next wave's
       // TRSM needs no event for it: its first step polls D[0], whose kernel has polled the last slice's counter.
       const bool colsl = pipe && sw.col_slices && own_diag && cntm > 0;
-      if (k > 0 && in_col && !(prev_colsl && pipe)) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
+      if (k > 0 && in_col && !(prev_colsl && pipe)) {
+        if (u1_target_last > 0) WRC(o.gate(ST_TRSM, o.sem(k - 1, sem_u1_done, sem_per_wave), u1_target_last));
+        else WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
+      }
       // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite its
       // set while TRSM(k) still reads the other
       const char *head = nullptr;
@@ -412,6 +420,7 @@ struct Walker {
           sy.su = (hipStream_t)o.stream(ST_U1);
           sy.sem = o.sem(k, 0, sem_per_wave);
           sy.col_slices = colsl;
+          sy.panel_done_all = sw.u1_counters && !colsl;
           if (flow) {
             sy.fc = o.sem(k, 3 * nbm + 1, sem_per_wave);
             sy.sflow = (hipStream_t)o.stream(ST_CX);
@@ -429,6 +438,7 @@ struct Walker {
         WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine && !head_flow ? ev(k, E_HEAD) : -1,
                     pipe || pipe_local ? &sy : nullptr, wait_sem, wait_target));
         if (head_flow) WRC(o.rec(ev(k, E_HEAD), ST_CX));  // (the head tile is complete when the row-slab launch is)
+        if (pipe) panel_target = sy.panel_target;
         if (mr && P > 1 && !last) {
           WRC(o.rec(ev(k, E_LKK), ST_PANEL));
           WRC(diag_send(k, lkk, (const char *)o.winv(par)));
@@ -635,11 +645,15 @@ struct Walker {
           WRC(o.diag_syrk(k, k + 1, ckk, head, ST_U1));
           WRC(o.rec(ev(k, E_U1D), ST_U1));
         }
-        if (!colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
+        // (in the latency form behind a counter when the panel raised one: no event on the cycle TRSM -> column update -> TRSM)
+        const bool u1c = u1s && panel_target > 0 && !head_flow;
+        if (u1c) WRC(o.gate(ST_U1, o.sem(k, 3 * nbm - 1, sem_per_wave), panel_target));
+        else if (!colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
         if (head_flow) WRC(o.wt(ST_U1, ev(k, E_HEAD)));
         if (halves && prof) WRC(o.rec(ev(k, E_PN0), ST_U1));
         if (u1s) {
-          WRC(o.update_col_small(k, ST_U1));
+          WRC(o.update_col_small(k, ST_U1, u1c ? o.sem(k, sem_u1_done, sem_per_wave) : nullptr));
+          if (u1c) u1_target_prev = n_r1o * (mb / 64) * (mb / 64);
         } else if (!colsl) {  // (else: column k+1 went out in slices behind the panel's steps)
           WRC(o.update(k, -1, k + 1, k + 2, 1, pk, nullptr, yield, ST_U1));
           if (n_r1o > 0) ++timed;

@@ -433,7 +433,16 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
                                  {"CHOLMI_PIPE_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
                                  {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"},
                                  # counters: every grid behind a gate kernel / every grid polling itself
-                                 {"CHOLMI_POLL_MAX_WGS": "0"}, {"CHOLMI_POLL_MAX_WGS": "100000"}])
+                                 {"CHOLMI_POLL_MAX_WGS": "0"}, {"CHOLMI_POLL_MAX_WGS": "100000"},
+                                 # counter-linked waves from the first one on: without the near column (column k+2 as a launch
+                                 # of its own) and the latency form of column k+1; with them (the default) and that launch
+                                 # behind counters instead of events; column slices on top
+                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_PIPE_NEAR": "0", "CHOLMI_U1_SMALL": "0"},
+                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64",
+                                  "CHOLMI_U1_COUNTERS": "1"},
+                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_COL_SLICES": "1"},
+                                 # ... entered behind waves launched as wider near / far halves
+                                 {"CHOLMI_PIPE_FACTOR": "0.3", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"}])
 def test_walker_schedule_variants_match_the_oracle(env, orc):
     """The walker picks its schedule by size (two panels per pass only while a wave's update is long, and so
     on), so at oracle-sized problems the default run never enters some of them.  Each variant forced through
@@ -478,6 +487,13 @@ FLOW_ALL = {"CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PA
     (2048, 256, dict(FLOW_ALL, CHOLMI_FLOW_MIN_NBM="2")),          # two
     (4096, 512, {"CHOLMI_FLOW_FACTOR": "0.05"}),                   # entered late: event-linked, counter-linked, then flow waves
     (4096, 512, {}),                                               # the default rule: chain-bound from wave 0 on -> flow
+    # the streaming row slabs (k_flow_rows2; measured alternatives, off by default): the diagonal tile's rows; the head
+    # tile's too; the whole panel's; with column slices behind them; three blocks per tile
+    (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="2", CHOLMI_NEAR_FACTOR="100")),
+    (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="3", CHOLMI_NEAR_FACTOR="100")),
+    (4096, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_NEAR_FACTOR="100")),
+    (4096, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_COL_SLICES="1", CHOLMI_NEAR_FACTOR="100")),
+    (3072, 384, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_FLOW_PANEL_MAX="3")),
 ])
 def test_flow_form_of_the_tile_potrf_matches_the_oracle(N, B, env, orc):
     """k_flow_factor / k_flow_rows (round 4): the tile POTRF of a counter-linked wave as two persistent launches whose
