@@ -91,7 +91,7 @@ struct WaveCalib {
 // switches of the schedule (environment, read once; CHOLMI_* names in DESIGN.md section 4)
 struct WaveSwitches {
   int pair_max_mb = 1024;
-  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0, near_fac = 0.7;
+  double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0, near_fac = 0.7, flow_run_fac = 1.0;
   bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false, pipe_near = true, u1_counters = false;
   int u1_small_max = 8;  // counter-linked waves: column k+1 in the latency form while it has at most this many tiles below the diagonal (CHOLMI_U1_SMALL)
   // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
@@ -104,6 +104,7 @@ struct WaveSwitches {
     if (const char *e = getenv("CHOLMI_YIELD_FACTOR")) yfac = atof(e);
     if (const char *e = getenv("CHOLMI_PIPE_FACTOR")) pipe_fac = atof(e);
     if (const char *e = getenv("CHOLMI_FLOW_FACTOR")) flow_fac = atof(e);
+    if (const char *e = getenv("CHOLMI_FLOW_RUN_FACTOR")) flow_run_fac = atof(e);
     if (const char *e = getenv("CHOLMI_HALVES_MAX_ROUNDS")) halves_max_rounds = atof(e);
     if (const char *e = getenv("CHOLMI_SYRK_PIPE")) syrk_pipe = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_HEAD_FIRST")) head_first = atoi(e) != 0;
@@ -352,7 +353,9 @@ struct Walker {
     // That edge runs on counters too (round 4): the TRSM steps are launched ahead and poll D[s] / I[s] instead of waiting
     // for an event per step; everything that crosses a transport call stays an event.
     const bool flags_local = mr && o.counters();
-    const bool flow_run = (double)g.tiles_in(1, nt) * cal.t_tile < sw.pipe_fac * cal.t_panel;
+    // (1.0 panel estimates: N <= ~9000-10000 at tile 512 -- with the near column and the latency-form column update of
+    // round 4 the form gains 7 % at N = 8192 and nothing at 12288; at 0.7 the rule flipped at 8192 with the box's calibration)
+    const bool flow_run = (double)g.tiles_in(1, nt) * cal.t_tile < sw.flow_run_fac * cal.t_panel;
     const int *wait_sem = nullptr;  // what this wave's first diagonal-block step polls, when the last wave raised it
     int wait_target = 0;
     const double b3 = (double)mb * mb * mb;
