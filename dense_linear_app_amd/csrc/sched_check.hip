@@ -1,0 +1,269 @@
+// Schedule checker (test infrastructure, no GPU needed): the wave walker of walker.h run over an Ops that executes
+// nothing and RECORDS -- every launch with the tiles it reads and writes, every event record / wait, every counter a
+// stream is gated on -- and then checks that any two launches that touch the same tile (or the same block-inverse
+// workspace), one of them writing, are ordered: by their stream, by an event, or by a counter.  The walker's
+// dependencies are per regime (pairs, near / far halves, counter-linked waves, the near column, the flow form ...) and a
+// missing one shows on the GPU only as a rare wrong digit; here it is a deterministic finding with the two launches'
+// names.  One GPU (p = q = 1) only: the transports of a grid are exercised by tests/test_dist_cabi_gloo.py.
+//
+// Granularity: o.panel() is one POTRF launch (ST_PANEL; with the flow form also ST_CX), one TRSM launch over the whole
+// panel (ST_TRSM, behind it), and in counter-linked waves one launch for the SYRK slices (ST_U1, behind the TRSM) --
+// what happens between those three is kernels.hip's business (launch_panel_pipelined) and is tested on the GPU.
+#include <bitset>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/cholmi.h"
+#include "cholmi_internal.h"
+#include "walker.h"
+
+using namespace cholmi;
+
+namespace {
+
+struct TraceOps {
+  const WaveGeo &g;
+  bool prof;
+  struct Op {
+    std::string name;
+    std::vector<std::pair<int, bool>> acc;  // (resource, written): tile (i, j) = i * nt + j, block inverses = nt * nt + parity
+    std::vector<int> deps;
+  };
+  std::vector<Op> ops;
+  int last_on[ST_COUNT];
+  std::set<int> pending[ST_COUNT];       // what the next launch of a stream has to follow beyond the stream's last one
+  std::map<int, std::set<int>> ev_deps;  // a recorded event: the launches it stands behind
+  std::map<const int *, int> producer;   // a counter: the launch that raises it to its target
+  std::vector<int> sems;
+  std::vector<std::string> findings;
+  int drop_wait = -1, drop_gate = -1, nwaits = 0, ngates = 0;
+  std::string dropped;  // self-test: the n-th event wait / gate is ignored
+  char *const fake_base = reinterpret_cast<char *>(uintptr_t(1) << 40);
+
+  TraceOps(const WaveGeo &geo, bool profiling) : g(geo), prof(profiling) {
+    for (int &l : last_on) l = -1;
+  }
+  bool profiling() const { return prof; }
+  bool pipe_ok() const { return true; }
+  bool counters() const { return !sems.empty(); }
+  bool can_split_trsm() const { return true; }
+  bool flow_ok() const { return true; }
+  void *flow_event() { return nullptr; }
+  void *stream(int st) { return reinterpret_cast<void *>(uintptr_t(st + 1)); }
+  char *tile(int il, int jl) { return fake_base + ((size_t)il + (size_t)jl * g.lmt) * g.tile_bytes; }
+  void *winv(int par) { return reinterpret_cast<void *>(uintptr_t(par + 1)); }
+  void *alloc(size_t) { return nullptr; }
+  int *sem(int k, int which, int per_wave) { return sems.data() + ((size_t)per_wave * k + which) * 32; }
+  int T(int i, int j) const { return i * g.nt + j; }
+
+  int begin(int, int nt, int sem_per_wave) {
+    sems.assign((size_t)nt * sem_per_wave * 32 + 32, 0);
+    return 0;
+  }
+  // a launch on the streams of `mask`: behind their last launches and everything they have been told to wait for
+  int add(unsigned mask, std::string name, std::vector<std::pair<int, bool>> acc, std::vector<int> extra = {}) {
+    Op op;
+    op.name = std::move(name);
+    op.acc = std::move(acc);
+    std::set<int> d(extra.begin(), extra.end());
+    for (int st = 0; st < ST_COUNT; ++st)
+      if (mask & (1u << st)) {
+        if (last_on[st] >= 0) d.insert(last_on[st]);
+        d.insert(pending[st].begin(), pending[st].end());
+        pending[st].clear();
+      }
+    d.erase(-1);
+    op.deps.assign(d.begin(), d.end());
+    ops.push_back(std::move(op));
+    const int id = (int)ops.size() - 1;
+    for (int st = 0; st < ST_COUNT; ++st)
+      if (mask & (1u << st)) last_on[st] = id;
+    return id;
+  }
+  int rec(int ev, int st) {
+    std::set<int> d = pending[st];
+    if (last_on[st] >= 0) d.insert(last_on[st]);
+    ev_deps[ev] = std::move(d);
+    return 0;
+  }
+  int wt(int st, int ev) {
+    if (nwaits++ == drop_wait) {
+      char b[120];
+      snprintf(b, sizeof b, "(dropped: stream %d's wait for event %d = wave %d kind %d)", st, ev, ev / 15, ev % 15);
+      dropped = b;
+      return 0;
+    }
+    auto it = ev_deps.find(ev);
+    if (it == ev_deps.end()) {
+      char b[160];
+      snprintf(b, sizeof b, "stream %d waits for event %d (wave %d, kind %d), which has not been recorded in this factorisation", st, ev,
+               ev / 15, ev % 15);
+      findings.push_back(b);
+      return 0;
+    }
+    pending[st].insert(it->second.begin(), it->second.end());
+    return 0;
+  }
+  int gate(int st, const int *sem, int) {
+    if (ngates++ == drop_gate) return 0;
+    auto it = producer.find(sem);
+    if (it == producer.end()) {
+      findings.push_back("a stream is gated on a counter nobody has been asked to raise");
+      return 0;
+    }
+    pending[st].insert(it->second);
+    return 0;
+  }
+  int signal(int st, int *sem) {
+    producer[sem] = add(1u << st, "signal", {});
+    return 0;
+  }
+  int panel(int k, char *, void *, char *, int ntiles, int, int ev_head, const SyrkPipe *sy, const int *wait_sem, int) {
+    const int nt = g.nt, W = nt * nt + (k & 1);
+    std::vector<int> extra;
+    if (wait_sem && ngates++ != drop_gate) {
+      auto it = producer.find(wait_sem);
+      if (it == producer.end()) findings.push_back("POTRF(" + std::to_string(k) + ") polls a counter nobody raises");
+      else extra.push_back(it->second);
+    }
+    const bool flow = sy && sy->fc && sy->sflow;
+    const int potrf = add((1u << ST_PANEL) | (flow ? 1u << ST_CX : 0u), "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow]" : ""),
+                          {{T(k, k), true}, {W, true}}, extra);
+    if (ntiles <= 0) return 0;
+    std::vector<std::pair<int, bool>> acc = {{T(k, k), false}, {W, false}};
+    for (int i = k + 1; i < nt; ++i) acc.push_back({T(i, k), true});
+    const bool head_flow = flow && sy->head_flow;
+    const int trsm = add((1u << ST_TRSM) | (head_flow ? 1u << ST_CX : 0u), "TRSM(" + std::to_string(k) + ")", acc, {potrf});
+    if (ev_head >= 0) ev_deps[ev_head] = {trsm};
+    if (sy && sy->sem) producer[sy->sem + 32 * (3 * g.nbm - 1)] = trsm;  // H[nbm-1] ("panel complete" when it counts every tile)
+    if (sy && sy->c && sy->su) {
+      std::vector<std::pair<int, bool>> sa = {{T(k + 1, k), false}, {T(k + 1, k + 1), true}};
+      if (sy->col_slices)
+        for (int i = k + 2; i < nt; ++i) sa.push_back({T(i, k), false}), sa.push_back({T(i, k + 1), true});
+      const int sl = add(1u << ST_U1, "SYRK slices(" + std::to_string(k) + ")", sa, {trsm});
+      producer[sy->sem + 32 * (3 * g.nbm)] = sl;
+    }
+    return 0;
+  }
+  int trsm(int k, char *, int, const char *, const char *, int st) {
+    std::vector<std::pair<int, bool>> acc = {{T(k, k), false}};
+    for (int i = k + 1; i < g.nt; ++i) acc.push_back({T(i, k), true});
+    add(1u << st, "TRSM(" + std::to_string(k) + ") [remote diagonal]", acc);
+    return 0;
+  }
+  int diag_syrk(int k, int j, char *, const char *, int st) {
+    add(1u << st, "SYRK(" + std::to_string(j) + "," + std::to_string(j) + ") by panel " + std::to_string(k), {{T(j, k), false}, {T(j, j), true}});
+    return 0;
+  }
+  int update(int k1, int k2, int jlo, int jhi, int what, const PanelRef &, const PanelRef *p2, bool, int st) {
+    const int nt = g.nt;
+    jlo = std::min(jlo, nt), jhi = std::min(jhi, nt);
+    std::vector<std::pair<int, bool>> acc;
+    std::set<int> rows;
+    for (int j = jlo; j < jhi; ++j) {
+      if (what & 2) acc.push_back({T(j, j), true}), rows.insert(j);
+      if (what & 1)
+        for (int i = j + 1; i < nt; ++i) acc.push_back({T(i, j), true}), rows.insert(i), rows.insert(j);
+    }
+    if (acc.empty()) return 0;
+    const int ks[2] = {k1, p2 ? k2 : -1};
+    for (int k : ks)
+      if (k >= 0)
+        for (int i : rows) acc.push_back({T(i, k), false});
+    char b[96];
+    snprintf(b, sizeof b, "update columns [%d,%d) %s by panel %d%s", jlo, jhi, what == 3 ? "" : what == 1 ? "(off-diagonal) " : "(diagonal) ", k1,
+             p2 ? (" and " + std::to_string(k2)).c_str() : "");
+    add(1u << st, b, acc);
+    return 0;
+  }
+  int update_col_small(int k, int st, int *done) {
+    std::vector<std::pair<int, bool>> acc = {{T(k + 1, k), false}};
+    for (int i = k + 2; i < g.nt; ++i) acc.push_back({T(i, k), false}), acc.push_back({T(i, k + 1), true});
+    const int id = add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
+    if (done) producer[done] = id;
+    return 0;
+  }
+  // every pair of launches on one resource, one of them writing: the earlier one must be an ancestor of the later one
+  int finish(int, int, const std::vector<std::pair<int, int>> &brackets, int *info) {
+    *info = 0;
+    for (auto &b : brackets)
+      if (!ev_deps.count(b.first) || !ev_deps.count(b.second)) {
+        // (a bracket of a wave that launched nothing: the product skips it as well)
+      }
+    const int n = (int)ops.size();
+    constexpr int MAXOPS = 16384;
+    if (n > MAXOPS) {
+      findings.push_back("too many launches for the checker");
+      return 0;
+    }
+    std::vector<std::bitset<MAXOPS>> *reach = new std::vector<std::bitset<MAXOPS>>(n);
+    for (int i = 0; i < n; ++i)
+      for (int d : ops[i].deps) {
+        (*reach)[i] |= (*reach)[d];
+        (*reach)[i].set(d);
+      }
+    std::map<int, std::vector<std::pair<int, bool>>> by_res;
+    for (int i = 0; i < n; ++i)
+      for (auto &a : ops[i].acc) by_res[a.first].push_back({i, a.second});
+    for (auto &kv : by_res) {
+      auto &v = kv.second;
+      for (size_t b = 1; b < v.size(); ++b)
+        for (size_t a = 0; a < b; ++a) {
+          if (v[a].first == v[b].first || (!v[a].second && !v[b].second)) continue;
+          if (!(*reach)[v[b].first].test(v[a].first)) {
+            char buf[400];
+            const int res = kv.first, nt = g.nt;
+            if (res < nt * nt)
+              snprintf(buf, sizeof buf, "tile (%d,%d): '%s' (%s) and '%s' (%s) are not ordered", res / nt, res % nt, ops[v[a].first].name.c_str(),
+                       v[a].second ? "writes" : "reads", ops[v[b].first].name.c_str(), v[b].second ? "writes" : "reads");
+            else
+              snprintf(buf, sizeof buf, "block inverses %d: '%s' (%s) and '%s' (%s) are not ordered", res - nt * nt, ops[v[a].first].name.c_str(),
+                       v[a].second ? "writes" : "reads", ops[v[b].first].name.c_str(), v[b].second ? "writes" : "reads");
+            if (findings.size() < 64) findings.push_back(buf);
+          }
+        }
+    }
+    delete reach;
+    return 0;
+  }
+};
+
+}  // namespace
+
+// Test hook (include/cholmi.h).  Returns the number of findings (0: every conflicting pair of launches is ordered),
+// < 0 when the walker itself failed; `report` receives the findings, one per line, and a last line with counts.
+extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap) {
+  if (nt <= 0 || mb < MACRO || mb % MACRO) return chol_internal_fail(-1, "schedule_check: nt > 0, mb a multiple of 128");
+  WaveGeo g;
+  g.init(nt, mb, 1, 1, 0, 8);
+  TraceOps ops(g, profiling != 0);
+  WaveCalib c;
+  c.t_tile = t_tile, c.t_panel = t_panel;
+  const int rows_saved = g_flow_rows;
+  if (const char *e = getenv("CHOLMI_FLOW_ROWS")) g_flow_rows = atoi(e);
+  // (self-test of the checker: CHOLMI_CHECK_DROP_WAIT / _DROP_GATE = n makes it ignore the n-th event wait / counter edge the
+  // walker asks for -- a schedule with that dependency missing, which it has to report unless the edge was redundant)
+  if (const char *e = getenv("CHOLMI_CHECK_DROP_WAIT")) ops.drop_wait = atoi(e);
+  if (const char *e = getenv("CHOLMI_CHECK_DROP_GATE")) ops.drop_gate = atoi(e);
+  Walker<TraceOps> w(ops, g, nullptr, c);
+  long long info = 0;
+  int rc = w.setup();
+  if (!rc) rc = w.run(&info);
+  g_flow_rows = rows_saved;
+  if (rc) return rc < 0 ? rc : -rc;
+  std::string out;
+  for (auto &f : ops.findings) out += f + "\n";
+  char tail[160];
+  snprintf(tail, sizeof tail, "%zu launches, %d event waits, %d counter edges, %d flow-form waves, %zu findings\n", ops.ops.size(), ops.nwaits,
+           ops.ngates, w.flow_waves, ops.findings.size());
+  out += tail;
+  if (!ops.dropped.empty()) out += ops.dropped + "\n";
+  if (report && cap > 0) {
+    snprintf(report, (size_t)cap, "%s", out.size() < (size_t)cap ? out.c_str() : out.substr(out.size() - cap + 1).c_str());
+  }
+  return (int)ops.findings.size();
+}

@@ -245,6 +245,17 @@ int chol_mfma_probe(int dtype, int waves_per_simd, double *tflops);
  * (two persistent launches handing 16-column panels to each other through polled counters). */
 int chol_debug_flow_waves(void);
 
+/* Test hook, no GPU needed: the wave walker (one GPU, nt x nt tiles of edge mb) run over an engine that executes nothing and
+ * records every launch with the tiles it reads and writes, every event record / wait and every counter a stream is gated
+ * on; then every pair of launches that touch the same tile (or block-inverse workspace), one of them writing, must be
+ * ordered by a stream, an event or a counter.  t_tile / t_panel [s]: the speeds the walker picks its regimes from (the
+ * CHOLMI_* schedule switches apply as in the product); profiling: with the per-wave event brackets.  Returns the number of
+ * findings (0 = every conflict ordered; < 0: the walker failed); `report` (cap bytes) receives them, one per line, and a
+ * last line "<launches> launches, <w> event waits, <c> counter edges, <n> flow-form waves, <m> findings".
+ * CHOLMI_CHECK_DROP_WAIT / CHOLMI_CHECK_DROP_GATE = n: the checker's self-test -- it ignores the n-th event wait / counter
+ * edge the walker asks for, i.e. checks a schedule with that dependency missing. */
+int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap);
+
 /* What the walker's regime switches (pairs / halves / counter-linked chain / CU hand-over) are measured in,
  * taken once at chol_init (or from CHOLMI_CALIB="tf64,us64,tf32,us32"): out8[0..3] = fp64 MFMA probe
  * [TFLOP/s], fp64 128 x 128 diagonal-block step alone [us], the same for fp32; out8[4..7] = the derived

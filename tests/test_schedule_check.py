@@ -1,0 +1,91 @@
+"""The wave walker's dependencies, checked without a GPU (csrc/sched_check.hip, chol_debug_schedule_check): the walker
+runs over an engine that records every launch with the tiles it reads and writes, every event record / wait and every
+counter edge, and any two launches that touch the same tile (or block-inverse workspace), one of them writing, must be
+ordered.  The schedule is picked per wave from measured speeds and a dozen CHOLMI_* switches:
+here every regime is forced at many sizes.  A missing dependency shows on the GPU as a rare wrong digit at best; here
+it is a deterministic finding that names the two launches."""
+import ctypes as C
+import re
+
+import pytest
+
+from dense_linear_app_amd._lib import lib
+
+T512, P512 = 3.8e-6, 700e-6  # seconds per tile update / per panel chain, about what chol_init measures at tile 512
+
+
+def check(nt, mb, t_tile, t_panel, profiling=0):
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().chol_debug_schedule_check(nt, mb, t_tile, t_panel, profiling, buf, len(buf))
+    rep = buf.value.decode()
+    m = re.search(r"(\d+) launches, (\d+) event waits, (\d+) counter edges, (\d+) flow-form waves, (\d+) findings", rep)
+    assert m, rep
+    return n, rep, [int(x) for x in m.groups()]
+
+
+SWITCHES = [
+    {},
+    {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"}, {"CHOLMI_PAIR_MAX_MB": "0"},
+    {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"},
+    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_PIPE_FACTOR": "0.02"}, {"CHOLMI_SYRK_PIPE": "0"},
+    {"CHOLMI_PIPE_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
+    {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_SPLIT_U1": "1"}, {"CHOLMI_YIELD_FACTOR": "0"},
+    # round 4: the near column, the latency form of column k+1 (also behind counters), column slices, the flow form late / never / always
+    {"CHOLMI_PIPE_NEAR": "0"}, {"CHOLMI_U1_SMALL": "0"}, {"CHOLMI_PIPE_NEAR": "0", "CHOLMI_U1_SMALL": "0"},
+    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64", "CHOLMI_U1_COUNTERS": "1"},
+    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_COL_SLICES": "1"},
+    {"CHOLMI_PIPE_FACTOR": "0.3", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
+    {"CHOLMI_NEAR_FACTOR": "0.3"}, {"CHOLMI_U1_COUNTERS": "1"}, {"CHOLMI_COL_SLICES": "1"},
+    {"CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_FLOW_FACTOR": "0.05"},
+    {"CHOLMI_FLOW_RUN_FACTOR": "0"}, {"CHOLMI_FLOW_RUN_FACTOR": "100"},
+    {"CHOLMI_FLOW_ROWS": "2"}, {"CHOLMI_FLOW_ROWS": "3"}, {"CHOLMI_FLOW_ROWS": "4", "CHOLMI_COL_SLICES": "1"},
+    {"CHOLMI_FLOW_ROWS": "4", "CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100"},
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
+def test_every_conflicting_pair_of_launches_is_ordered(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    launches = 0
+    for mb, t_tile, t_panel in ((512, T512, P512), (384, 1.6e-6, 570e-6), (256, 0.5e-6, 350e-6), (1024, 30e-6, 1400e-6), (128, 0.06e-6, 180e-6)):
+        for nt in (1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 24, 33, 48):
+            for scale in (1.0, 0.05, 20.0):  # the same matrix on a chip whose panel chain is 20x faster / slower against its update
+                for prof in (0, 1):
+                    n, rep, cnt = check(nt, mb, t_tile, t_panel * scale, prof)
+                    assert n == 0, (env, nt, mb, scale, prof, rep)
+                    launches += cnt[0]
+    assert launches > 10000
+
+
+def test_the_regimes_are_really_entered():
+    """Counts that tell the forced regimes apart (otherwise the sweep above would pass on one schedule)."""
+    _, _, d = check(8, 512, T512, P512)           # N = 4096 at tile 512: chain-bound from wave 0 on -> flow form, counters
+    assert d[3] == 7 and d[2] >= 7, d
+    _, _, d = check(32, 512, T512, P512)          # N = 16384: pairs, halves, then counter-linked waves, no flow form
+    assert d[3] == 0 and d[2] >= 5, d
+    _, _, e = check(32, 512, T512, P512 * 1e-3)   # a panel chain that costs nothing: nothing but pairs / plain waves, no counters
+    assert e[2] == 0 and e[0] < d[0], (d, e)
+    _, _, d = check(8, 1024, 30e-6, 1400e-6)      # eight blocks per tile: never the flow form
+    assert d[3] == 0, d
+
+
+@pytest.mark.parametrize("nt,mb,t_tile,t_panel", [(12, 512, T512, P512), (20, 512, T512, P512), (24, 512, T512, P512 * 0.2), (16, 256, 0.5e-6, 350e-6)])
+def test_the_checker_sees_a_missing_dependency(nt, mb, t_tile, t_panel, monkeypatch):
+    """Self-test by mutation: the checker ignores ONE dependency the walker asked for and must then report a conflict --
+    for every counter edge, and for the event waits that are not implied by others (measured: the start / join waits of
+    every stream, and per wave the waits whose producer the consumer already follows through a third launch)."""
+    n, rep, cnt = check(nt, mb, t_tile, t_panel)
+    assert n == 0, rep
+    nwaits, ngates = cnt[1], cnt[2]
+    for i in range(ngates):
+        monkeypatch.setenv("CHOLMI_CHECK_DROP_GATE", str(i))
+        n, rep, _ = check(nt, mb, t_tile, t_panel)
+        assert n > 0, (i, rep)
+    monkeypatch.delenv("CHOLMI_CHECK_DROP_GATE", raising=False)
+    seen = 0
+    for i in range(nwaits):
+        monkeypatch.setenv("CHOLMI_CHECK_DROP_WAIT", str(i))
+        n, rep, _ = check(nt, mb, t_tile, t_panel)
+        seen += n > 0
+    assert seen >= 0.4 * nwaits, (seen, nwaits)
