@@ -4,7 +4,8 @@
 // workspace), one of them writing, are ordered: by their stream, by an event, or by a counter.  The walker's
 // dependencies are per regime (pairs, near / far halves, counter-linked waves, the near column, the flow form ...) and a
 // missing one shows on the GPU only as a rare wrong digit; here it is a deterministic finding with the two launches'
-// names.  One GPU (p = q = 1) only: the transports of a grid are exercised by tests/test_dist_cabi_gloo.py.
+// names.  On a p x q grid the check is per rank: sends read and receives write (tiles and the rotating receive buffers) on
+// the stream they are issued on; what the OTHER ranks do is tests/test_dist_cabi_gloo.py's business.
 //
 // Granularity: o.panel() is one POTRF launch (ST_PANEL; with the flow form also ST_CX), one TRSM launch over the whole
 // panel (ST_TRSM, behind it), and in counter-linked waves one launch for the SYRK slices (ST_U1, behind the TRSM) --
@@ -30,7 +31,7 @@ struct TraceOps {
   bool prof;
   struct Op {
     std::string name;
-    std::vector<std::pair<int, bool>> acc;  // (resource, written): tile (i, j) = i * nt + j, block inverses = nt * nt + parity
+    std::vector<std::pair<long, bool>> acc;  // (slot, written): tile-sized slots of a made-up address space, see slot_of
     std::vector<int> deps;
   };
   std::vector<Op> ops;
@@ -40,12 +41,17 @@ struct TraceOps {
   std::map<const int *, int> producer;   // a counter: the launch that raises it to its target
   std::vector<int> sems;
   std::vector<std::string> findings;
-  int drop_wait = -1, drop_gate = -1, nwaits = 0, ngates = 0;
-  std::string dropped;  // self-test: the n-th event wait / gate is ignored
+  int drop_wait = -1, drop_gate = -1, nwaits = 0, ngates = 0;  // self-test: the n-th event wait / gate is ignored
+  std::string dropped;
+  // the address space: this rank's lmt x lnt tiles, the two block-inverse workspaces, then whatever the walker allocates
+  // (receive buffers of a grid), all in units of one tile
   char *const fake_base = reinterpret_cast<char *>(uintptr_t(1) << 40);
+  long local_slots = 0, next_slot = 0;
 
   TraceOps(const WaveGeo &geo, bool profiling) : g(geo), prof(profiling) {
     for (int &l : last_on) l = -1;
+    local_slots = (long)g.lmt * std::max(1, g.lnt);
+    next_slot = local_slots + 2;
   }
   bool profiling() const { return prof; }
   bool pipe_ok() const { return true; }
@@ -54,18 +60,41 @@ struct TraceOps {
   bool flow_ok() const { return true; }
   void *flow_event() { return nullptr; }
   void *stream(int st) { return reinterpret_cast<void *>(uintptr_t(st + 1)); }
+  static int stream_id(void *s) { return (int)reinterpret_cast<uintptr_t>(s) - 1; }
   char *tile(int il, int jl) { return fake_base + ((size_t)il + (size_t)jl * g.lmt) * g.tile_bytes; }
-  void *winv(int par) { return reinterpret_cast<void *>(uintptr_t(par + 1)); }
-  void *alloc(size_t) { return nullptr; }
+  void *winv(int par) { return fake_base + (size_t)(local_slots + par) * g.tile_bytes; }
+  void *alloc(size_t bytes) {
+    char *p = fake_base + (size_t)next_slot * g.tile_bytes;
+    next_slot += (long)((bytes + g.tile_bytes - 1) / g.tile_bytes);
+    return p;
+  }
   int *sem(int k, int which, int per_wave) { return sems.data() + ((size_t)per_wave * k + which) * 32; }
-  int T(int i, int j) const { return i * g.nt + j; }
+  using Acc = std::vector<std::pair<long, bool>>;
+  void touch(Acc &a, const void *ptr, size_t bytes, bool write) const {
+    if (!ptr || !bytes) return;
+    const long s0 = (long)(((const char *)ptr - fake_base) / (long)g.tile_bytes);
+    const long s1 = (long)(((const char *)ptr + bytes - 1 - fake_base) / (long)g.tile_bytes);
+    for (long t = s0; t <= s1; ++t) a.push_back({t, write});
+  }
+  std::string slot_name(long t) const {
+    char b[96];
+    if (t < local_slots) {
+      const int il = (int)(t % g.lmt), jl = (int)(t / g.lmt);
+      snprintf(b, sizeof b, "tile (%d,%d)", il * g.P + g.pr, jl * g.Q + g.pc);
+    } else if (t < local_slots + 2) {
+      snprintf(b, sizeof b, "block inverses %ld", t - local_slots);
+    } else {
+      snprintf(b, sizeof b, "receive buffer slot %ld", t - local_slots - 2);
+    }
+    return b;
+  }
 
   int begin(int, int nt, int sem_per_wave) {
     sems.assign((size_t)nt * sem_per_wave * 32 + 32, 0);
     return 0;
   }
   // a launch on the streams of `mask`: behind their last launches and everything they have been told to wait for
-  int add(unsigned mask, std::string name, std::vector<std::pair<int, bool>> acc, std::vector<int> extra = {}) {
+  int add(unsigned mask, std::string name, Acc acc, std::vector<int> extra = {}) {
     Op op;
     op.name = std::move(name);
     op.acc = std::move(acc);
@@ -122,8 +151,7 @@ struct TraceOps {
     producer[sem] = add(1u << st, "signal", {});
     return 0;
   }
-  int panel(int k, char *, void *, char *, int ntiles, int, int ev_head, const SyrkPipe *sy, const int *wait_sem, int) {
-    const int nt = g.nt, W = nt * nt + (k & 1);
+  int panel(int k, char *lkk, void *wv, char *tiles, int ntiles, int, int ev_head, const SyrkPipe *sy, const int *wait_sem, int) {
     std::vector<int> extra;
     if (wait_sem && ngates++ != drop_gate) {
       auto it = producer.find(wait_sem);
@@ -131,71 +159,107 @@ struct TraceOps {
       else extra.push_back(it->second);
     }
     const bool flow = sy && sy->fc && sy->sflow;
-    const int potrf = add((1u << ST_PANEL) | (flow ? 1u << ST_CX : 0u), "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow]" : ""),
-                          {{T(k, k), true}, {W, true}}, extra);
+    Acc pa;
+    touch(pa, lkk, g.tile_bytes, true);
+    touch(pa, wv, std::max<size_t>(1, g.winv_bytes), true);
+    const int potrf = add((1u << ST_PANEL) | (flow ? 1u << ST_CX : 0u), "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow]" : ""), pa, extra);
     if (ntiles <= 0) return 0;
-    std::vector<std::pair<int, bool>> acc = {{T(k, k), false}, {W, false}};
-    for (int i = k + 1; i < nt; ++i) acc.push_back({T(i, k), true});
+    Acc acc;
+    touch(acc, lkk, g.tile_bytes, false);
+    touch(acc, wv, std::max<size_t>(1, g.winv_bytes), false);
+    touch(acc, tiles, (size_t)ntiles * g.tile_bytes, true);
     const bool head_flow = flow && sy->head_flow;
     const int trsm = add((1u << ST_TRSM) | (head_flow ? 1u << ST_CX : 0u), "TRSM(" + std::to_string(k) + ")", acc, {potrf});
     if (ev_head >= 0) ev_deps[ev_head] = {trsm};
     if (sy && sy->sem) producer[sy->sem + 32 * (3 * g.nbm - 1)] = trsm;  // H[nbm-1] ("panel complete" when it counts every tile)
-    if (sy && sy->c && sy->su) {
-      std::vector<std::pair<int, bool>> sa = {{T(k + 1, k), false}, {T(k + 1, k + 1), true}};
-      if (sy->col_slices)
-        for (int i = k + 2; i < nt; ++i) sa.push_back({T(i, k), false}), sa.push_back({T(i, k + 1), true});
+    if (sy && sy->c && sy->su) {  // (one GPU: the tiles of a column are contiguous)
+      Acc sa;
+      touch(sa, tiles, g.tile_bytes, false);
+      touch(sa, sy->c, g.tile_bytes, true);
+      if (sy->col_slices && ntiles > 1) {
+        touch(sa, tiles + g.tile_bytes, (size_t)(ntiles - 1) * g.tile_bytes, false);
+        touch(sa, (char *)sy->c + g.tile_bytes, (size_t)(ntiles - 1) * g.tile_bytes, true);
+      }
       const int sl = add(1u << ST_U1, "SYRK slices(" + std::to_string(k) + ")", sa, {trsm});
       producer[sy->sem + 32 * (3 * g.nbm)] = sl;
     }
     return 0;
   }
-  int trsm(int k, char *, int, const char *, const char *, int st) {
-    std::vector<std::pair<int, bool>> acc = {{T(k, k), false}};
-    for (int i = k + 1; i < g.nt; ++i) acc.push_back({T(i, k), true});
-    add(1u << st, "TRSM(" + std::to_string(k) + ") [remote diagonal]", acc);
+  int trsm(int k, char *tiles, int ntiles, const char *lkk, const char *wv, int st) {
+    Acc acc;
+    touch(acc, lkk, g.tile_bytes, false);
+    touch(acc, wv, std::max<size_t>(1, g.winv_bytes), false);
+    touch(acc, tiles, (size_t)ntiles * g.tile_bytes, true);
+    add(1u << st, "TRSM(" + std::to_string(k) + ") of " + std::to_string(ntiles) + " tiles [received diagonal tile]", acc);
     return 0;
   }
-  int diag_syrk(int k, int j, char *, const char *, int st) {
-    add(1u << st, "SYRK(" + std::to_string(j) + "," + std::to_string(j) + ") by panel " + std::to_string(k), {{T(j, k), false}, {T(j, j), true}});
+  int diag_syrk(int k, int j, char *Cjj, const char *A, int st) {
+    Acc acc;
+    touch(acc, A, g.tile_bytes, false);
+    touch(acc, Cjj, g.tile_bytes, true);
+    add(1u << st, "SYRK(" + std::to_string(j) + "," + std::to_string(j) + ") by panel " + std::to_string(k), acc);
     return 0;
   }
-  int update(int k1, int k2, int jlo, int jhi, int what, const PanelRef &, const PanelRef *p2, bool, int st) {
+  const char *ptile(const PanelRef &p, int i) const {
+    return (const char *)p.base[i % g.P] + (size_t)(i / g.P - p.first[i % g.P]) * g.tile_bytes;
+  }
+  int update(int k1, int k2, int jlo, int jhi, int what, const PanelRef &p1, const PanelRef *p2, bool, int st) {
     const int nt = g.nt;
     jlo = std::min(jlo, nt), jhi = std::min(jhi, nt);
-    std::vector<std::pair<int, bool>> acc;
+    Acc acc;
     std::set<int> rows;
     for (int j = jlo; j < jhi; ++j) {
-      if (what & 2) acc.push_back({T(j, j), true}), rows.insert(j);
-      if (what & 1)
-        for (int i = j + 1; i < nt; ++i) acc.push_back({T(i, j), true}), rows.insert(i), rows.insert(j);
+      if (j % g.Q != g.pc) continue;
+      for (int i = j; i < nt; ++i) {
+        if (i % g.P != g.pr || !(i == j ? (what & 2) : (what & 1))) continue;
+        touch(acc, tile(i / g.P, j / g.Q), g.tile_bytes, true);
+        rows.insert(i), rows.insert(j);
+      }
     }
     if (acc.empty()) return 0;
-    const int ks[2] = {k1, p2 ? k2 : -1};
-    for (int k : ks)
-      if (k >= 0)
-        for (int i : rows) acc.push_back({T(i, k), false});
-    char b[96];
-    snprintf(b, sizeof b, "update columns [%d,%d) %s by panel %d%s", jlo, jhi, what == 3 ? "" : what == 1 ? "(off-diagonal) " : "(diagonal) ", k1,
-             p2 ? (" and " + std::to_string(k2)).c_str() : "");
+    const PanelRef *ps[2] = {&p1, (p2 && k2 >= 0) ? p2 : nullptr};
+    for (const PanelRef *p : ps)
+      if (p)
+        for (int i : rows) touch(acc, ptile(*p, i), g.tile_bytes, false);
+    char b[120];
+    snprintf(b, sizeof b, "update columns [%d,%d) %sby panel %d%s", jlo, jhi, what == 3 ? "" : what == 1 ? "(off-diagonal) " : "(diagonal) ", k1,
+             ps[1] ? (" and " + std::to_string(k2)).c_str() : "");
     add(1u << st, b, acc);
     return 0;
   }
   int update_col_small(int k, int st, int *done) {
-    std::vector<std::pair<int, bool>> acc = {{T(k + 1, k), false}};
-    for (int i = k + 2; i < g.nt; ++i) acc.push_back({T(i, k), false}), acc.push_back({T(i, k + 1), true});
+    const int n = g.nt - k - 2;
+    Acc acc;
+    touch(acc, tile(k + 1, k), g.tile_bytes, false);
+    touch(acc, tile(k + 2, k), (size_t)n * g.tile_bytes, false);
+    touch(acc, tile(k + 2, k + 1), (size_t)n * g.tile_bytes, true);
     const int id = add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
     if (done) producer[done] = id;
     return 0;
   }
-  // every pair of launches on one resource, one of them writing: the earlier one must be an ancestor of the later one
-  int finish(int, int, const std::vector<std::pair<int, int>> &brackets, int *info) {
+  // the transport of a grid: a send reads, a receive writes, on the stream it is issued on
+  static int t_begin(void *) { return 0; }
+  static int t_end(void *) { return 0; }
+  static int t_allreduce(void *, long long *) { return 0; }
+  static int t_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream) {
+    TraceOps *o = (TraceOps *)ctx;
+    Acc acc;
+    o->touch(acc, buf, bytes, false);
+    o->add(1u << stream_id(stream), "send to rank " + std::to_string(peer), acc);
+    return 0;
+  }
+  static int t_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream) {
+    TraceOps *o = (TraceOps *)ctx;
+    Acc acc;
+    o->touch(acc, buf, bytes, true);
+    o->add(1u << stream_id(stream), "receive from rank " + std::to_string(peer), acc);
+    return 0;
+  }
+  // every pair of launches on one slot, one of them writing: the earlier one must be an ancestor of the later one
+  int finish(int, int, const std::vector<std::pair<int, int>> &, int *info) {
     *info = 0;
-    for (auto &b : brackets)
-      if (!ev_deps.count(b.first) || !ev_deps.count(b.second)) {
-        // (a bracket of a wave that launched nothing: the product skips it as well)
-      }
     const int n = (int)ops.size();
-    constexpr int MAXOPS = 16384;
+    constexpr int MAXOPS = 32768;
     if (n > MAXOPS) {
       findings.push_back("too many launches for the checker");
       return 0;
@@ -206,7 +270,7 @@ struct TraceOps {
         (*reach)[i] |= (*reach)[d];
         (*reach)[i].set(d);
       }
-    std::map<int, std::vector<std::pair<int, bool>>> by_res;
+    std::map<long, std::vector<std::pair<int, bool>>> by_res;
     for (int i = 0; i < n; ++i)
       for (auto &a : ops[i].acc) by_res[a.first].push_back({i, a.second});
     for (auto &kv : by_res) {
@@ -215,14 +279,9 @@ struct TraceOps {
         for (size_t a = 0; a < b; ++a) {
           if (v[a].first == v[b].first || (!v[a].second && !v[b].second)) continue;
           if (!(*reach)[v[b].first].test(v[a].first)) {
-            char buf[400];
-            const int res = kv.first, nt = g.nt;
-            if (res < nt * nt)
-              snprintf(buf, sizeof buf, "tile (%d,%d): '%s' (%s) and '%s' (%s) are not ordered", res / nt, res % nt, ops[v[a].first].name.c_str(),
-                       v[a].second ? "writes" : "reads", ops[v[b].first].name.c_str(), v[b].second ? "writes" : "reads");
-            else
-              snprintf(buf, sizeof buf, "block inverses %d: '%s' (%s) and '%s' (%s) are not ordered", res - nt * nt, ops[v[a].first].name.c_str(),
-                       v[a].second ? "writes" : "reads", ops[v[b].first].name.c_str(), v[b].second ? "writes" : "reads");
+            char buf[480];
+            snprintf(buf, sizeof buf, "%s: '%s' (%s) and '%s' (%s) are not ordered", slot_name(kv.first).c_str(), ops[v[a].first].name.c_str(),
+                     v[a].second ? "writes" : "reads", ops[v[b].first].name.c_str(), v[b].second ? "writes" : "reads");
             if (findings.size() < 64) findings.push_back(buf);
           }
         }
@@ -236,10 +295,12 @@ struct TraceOps {
 
 // Test hook (include/cholmi.h).  Returns the number of findings (0: every conflicting pair of launches is ordered),
 // < 0 when the walker itself failed; `report` receives the findings, one per line, and a last line with counts.
-extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap) {
+extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
+                                              char *report, int cap) {
   if (nt <= 0 || mb < MACRO || mb % MACRO) return chol_internal_fail(-1, "schedule_check: nt > 0, mb a multiple of 128");
+  if (p < 1 || q < 1 || p > MAXP || rank < 0 || rank >= p * q) return chol_internal_fail(-2, "schedule_check: grid");
   WaveGeo g;
-  g.init(nt, mb, 1, 1, 0, 8);
+  g.init(nt, mb, p, q, rank, 8);
   TraceOps ops(g, profiling != 0);
   WaveCalib c;
   c.t_tile = t_tile, c.t_panel = t_panel;
@@ -249,7 +310,16 @@ extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t
   // walker asks for -- a schedule with that dependency missing, which it has to report unless the edge was redundant)
   if (const char *e = getenv("CHOLMI_CHECK_DROP_WAIT")) ops.drop_wait = atoi(e);
   if (const char *e = getenv("CHOLMI_CHECK_DROP_GATE")) ops.drop_gate = atoi(e);
-  Walker<TraceOps> w(ops, g, nullptr, c);
+  WaveComm cm;
+  for (int ch = 0; ch < 2; ++ch) {
+    cm.ch[ch].ctx = &ops;
+    cm.ch[ch].group_begin = TraceOps::t_begin;
+    cm.ch[ch].send = TraceOps::t_send;
+    cm.ch[ch].recv = TraceOps::t_recv;
+    cm.ch[ch].group_end = TraceOps::t_end;
+    cm.ch[ch].allreduce_max = TraceOps::t_allreduce;
+  }
+  Walker<TraceOps> w(ops, g, p * q > 1 ? &cm : nullptr, c);
   long long info = 0;
   int rc = w.setup();
   if (!rc) rc = w.run(&info);
@@ -257,13 +327,14 @@ extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t
   if (rc) return rc < 0 ? rc : -rc;
   std::string out;
   for (auto &f : ops.findings) out += f + "\n";
-  char tail[160];
+  char tail[200];
   snprintf(tail, sizeof tail, "%zu launches, %d event waits, %d counter edges, %d flow-form waves, %zu findings\n", ops.ops.size(), ops.nwaits,
            ops.ngates, w.flow_waves, ops.findings.size());
   out += tail;
   if (!ops.dropped.empty()) out += ops.dropped + "\n";
-  if (report && cap > 0) {
-    snprintf(report, (size_t)cap, "%s", out.size() < (size_t)cap ? out.c_str() : out.substr(out.size() - cap + 1).c_str());
-  }
+  if (report && cap > 0) snprintf(report, (size_t)cap, "%s", out.size() < (size_t)cap ? out.c_str() : out.substr(out.size() - cap + 1).c_str());
   return (int)ops.findings.size();
+}
+extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap) {
+  return chol_debug_schedule_check_grid(nt, mb, 1, 1, 0, t_tile, t_panel, profiling, report, cap);
 }

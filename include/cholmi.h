@@ -255,6 +255,10 @@ int chol_debug_flow_waves(void);
  * CHOLMI_CHECK_DROP_WAIT / CHOLMI_CHECK_DROP_GATE = n: the checker's self-test -- it ignores the n-th event wait / counter
  * edge the walker asks for, i.e. checks a schedule with that dependency missing. */
 int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap);
+/* ... and rank `rank`'s share of the same factorisation on a p x q grid: its sends read and its receives write (tiles, the
+ * diagonal / head tile buffers by wave parity, the panel buffers by wave mod 4) on the streams they are issued on. */
+int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
+                                   char *report, int cap);
 
 /* What the walker's regime switches (pairs / halves / counter-linked chain / CU hand-over) are measured in,
  * taken once at chol_init (or from CHOLMI_CALIB="tf64,us64,tf32,us32"): out8[0..3] = fp64 MFMA probe

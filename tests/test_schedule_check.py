@@ -14,9 +14,9 @@ from dense_linear_app_amd._lib import lib
 T512, P512 = 3.8e-6, 700e-6  # seconds per tile update / per panel chain, about what chol_init measures at tile 512
 
 
-def check(nt, mb, t_tile, t_panel, profiling=0):
+def check(nt, mb, t_tile, t_panel, profiling=0, grid=(1, 1), rank=0):
     buf = C.create_string_buffer(1 << 16)
-    n = lib().chol_debug_schedule_check(nt, mb, t_tile, t_panel, profiling, buf, len(buf))
+    n = lib().chol_debug_schedule_check_grid(nt, mb, grid[0], grid[1], rank, t_tile, t_panel, profiling, buf, len(buf))
     rep = buf.value.decode()
     m = re.search(r"(\d+) launches, (\d+) event waits, (\d+) counter edges, (\d+) flow-form waves, (\d+) findings", rep)
     assert m, rep
@@ -89,3 +89,41 @@ def test_the_checker_sees_a_missing_dependency(nt, mb, t_tile, t_panel, monkeypa
         n, rep, _ = check(nt, mb, t_tile, t_panel)
         seen += n > 0
     assert seen >= 0.4 * nwaits, (seen, nwaits)
+
+
+GRID_SWITCHES = [{}, {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"}, {"CHOLMI_PAIR_MAX_MB": "0"},
+                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_SYRK_PIPE": "0"}, {"CHOLMI_HEAD_FIRST": "0"},
+                 {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_SPLIT_U1": "1"}]
+
+
+@pytest.mark.parametrize("env", GRID_SWITCHES, ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
+def test_every_rank_of_a_grid_orders_its_launches_sends_and_receives(env, monkeypatch):
+    """Per rank of a p x q grid: a send reads and a receive writes on the stream it is issued on -- tiles, the diagonal /
+    head tile buffers (by wave parity) and the panel buffers (by wave mod 4): the rotating buffers' reuse is exactly what a
+    timing-dependent test cannot pin down."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    checks = 0
+    for grid in ((2, 1), (1, 2), (2, 2), (4, 2), (2, 4), (3, 2), (4, 1), (3, 3)):
+        for nt in (1, 2, 3, 5, 8, 13, 24, 40):
+            for mb, t_tile, t_panel in ((512, T512, P512), (1024, 30e-6, 1400e-6), (128, 0.06e-6, 180e-6)):
+                for scale in (1.0, 0.05, 20.0):
+                    for rank in range(grid[0] * grid[1]):
+                        n, rep, _ = check(nt, mb, t_tile, t_panel * scale, rank & 1, grid, rank)
+                        assert n == 0, (env, grid, rank, nt, mb, scale, rep)
+                        checks += 1
+    assert checks > 3000
+
+
+@pytest.mark.parametrize("grid,rank", [((2, 2), 0), ((2, 2), 3), ((4, 2), 3), ((2, 1), 1)])
+def test_the_checker_sees_a_missing_dependency_on_a_grid(grid, rank, monkeypatch):
+    n, rep, cnt = check(16, 512, T512, P512, 0, grid, rank)
+    assert n == 0, rep
+    seen = 0
+    for i in range(cnt[1]):
+        monkeypatch.setenv("CHOLMI_CHECK_DROP_WAIT", str(i))
+        n, rep, _ = check(16, 512, T512, P512, 0, grid, rank)
+        seen += n > 0
+    # (the rest are implied by other paths: the start / join waits, the panel buffers' last readers -- wave k's panel needs every
+    # earlier update of its column anyway -- and the waits that keep POTRF(k+2) off block inverses that are still travelling)
+    assert seen >= 0.4 * cnt[1], (seen, cnt[1])
