@@ -640,7 +640,8 @@ struct Walker {
       WRC(o.wt(ST_MAIN, ev(k, E_PANEL)));
       if (head_flow) WRC(o.wt(ST_MAIN, ev(k, E_HEAD)));
       int timed = 0;  // k_trail_update launches inside this wave's profiling bracket
-      const bool u1s = pipe && !colsl && !mr && n_r1o > 0 && n_r1o <= sw.u1_small_max;
+      // (... of tiles up to 512: with 1024 tiles the form lost 2-4 % -- 256 workgroups per tile, K = 1024 each)
+      const bool u1s = pipe && !colsl && !mr && nbm <= 4 && n_r1o > 0 && n_r1o <= sw.u1_small_max;
       if (split) {
         // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
         // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
