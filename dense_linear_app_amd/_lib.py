@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
         "chol_extract_block": ([vp, i, i, i, i, i, vp], None),
         "chol_parse_payloads": ([C.c_char_p, vp, i, vp, vp, vp, vp], i),
         "chol_debug_flow_waves": ([], i),
+        "chol_last_potrf_regimes": ([C.POINTER(i), C.POINTER(i)], i),
         "chol_debug_schedule_check": ([i, i, d, d, i, C.c_char_p, i], i),
         "chol_debug_schedule_check_grid": ([i, i, i, i, i, d, d, i, C.c_char_p, i], i),
         "chol_last_potrf_stats": ([C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(d)], i),

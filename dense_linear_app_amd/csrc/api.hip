@@ -285,14 +285,10 @@ int build_worklist(chol_desc *d) {
   std::vector<int2> off, dg;
   d->ge.assign(d->nt + 2, 0);
   d->gd.assign(d->nt + 2, 0);
-  // diagnostic only (single-process descriptors): keep the diagonal tiles where the column order
-  // puts them, to measure what moving them to the end of a launch buys
-  const char *ord = getenv("CHOLMI_LIST_ORDER");
-  const bool interleaved = ord && !strcmp(ord, "interleaved") && d->p * d->q == 1;
   for (int J = d->nt - 1; J >= 0; --J) {
     if (J % d->q == d->pcol)
       for (int I = J; I < d->mt; ++I)
-        if (I % d->p == d->prow) ((I == J && !interleaved) ? dg : off).push_back(make_int2(I, J));
+        if (I % d->p == d->prow) (I == J ? dg : off).push_back(make_int2(I, J));
     d->ge[J] = (int)off.size();
     d->gd[J] = (int)dg.size();
   }
@@ -571,8 +567,7 @@ int rank_ctx_create(RankCtx *r, int device, const RankCtx *calib_from) {
     // (ST_MAIN; ST_U1): such a launch, longer than one round of workgroups, holds back every kernel of a stream behind
     // the same pipe until its last workgroup is placed (kernels.hip: k_pipe_big).  Probe the pairs; replace a victim
     // by a fresh stream (the old one is kept, so that its queue is not handed out again) and probe again.
-    const char *e = getenv("CHOLMI_PIPE_PROBE");
-    if (!e || atoi(e) != 0) {
+    {
       hipDeviceProp_t prop;
       HIPCHECK(hipGetDeviceProperties(&prop, device));
       unsigned long long *t = nullptr;
@@ -745,8 +740,6 @@ int chol_init(int ncpu, int ngpu) {
   }
   if (g.r.device >= count) return fail(CHOL_ERR_NO_GPU, "chol_init: device index out of range");
   HIPCHECK(hipSetDevice(g.r.device));
-  if (const char *e = getenv("CHOLMI_VARIANT")) cholmi::g_variant = atoi(e);
-  if (const char *e = getenv("CHOLMI_INTILE")) cholmi::g_intile_small = strcmp(e, "big") != 0;
   if (const char *e = getenv("CHOLMI_TRSM_SMALL_MAX")) cholmi::g_trsm_small_max = atoi(e);
   {
     // grids that may poll a counter themselves: few enough that, one per CU in the worst case, most CUs
@@ -757,28 +750,18 @@ int chol_init(int ncpu, int ngpu) {
     cholmi::g_poll_max_wgs = room < 0 ? 0 : (room < 48 ? room : 48);
   }
   if (const char *e = getenv("CHOLMI_POLL_MAX_WGS")) cholmi::g_poll_max_wgs = atoi(e);
-  if (const char *e = getenv("CHOLMI_PERSIST")) cholmi::g_persist = atoi(e);
   if (const char *e = getenv("CHOLMI_FLOW")) cholmi::g_flow = atoi(e);
-  if (const char *e = getenv("CHOLMI_FLOW_MAX_NBM")) cholmi::g_flow_max_nbm = std::min(8, atoi(e));
-  if (const char *e = getenv("CHOLMI_FLOW_MIN_NBM")) cholmi::g_flow_min_nbm = std::max(2, atoi(e));
-  if (const char *e = getenv("CHOLMI_FLOW_FENCES")) cholmi::g_flow_fences = atoi(e);
-  if (const char *e = getenv("CHOLMI_FLOW_ROWS")) cholmi::g_flow_rows = atoi(e);
-  if (const char *e = getenv("CHOLMI_FLOW_PANEL_MAX")) cholmi::g_flow_panel_max = atoi(e);
-  if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
-  if (const char *e = getenv("CHOLMI_INTILE_FUSED_MAX")) cholmi::g_intile_fused_max = atoi(e);
-  if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
-  if (const char *e = getenv("CHOLMI_TRSM_FUSED_MIN")) cholmi::g_trsm_fused_min = atoi(e);
-  if (const char *e = getenv("CHOLMI_LATE_DMA")) cholmi::g_late_dma = atoi(e);
-  if (const char *e = getenv("CHOLMI_F32_W8")) cholmi::g_f32_w8 = atoi(e);
-  HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
-  {
-    const char *e = getenv("CHOLMI_YIELD");
-    if (!e || atoi(e) != 0) {
-      HIPCHECK(hipMalloc(&g.d_ytab, YTAB_ENTRIES * sizeof(int)));
-      HIPCHECK(hipMemset(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int)));
-      cholmi::g_ytab = g.d_ytab;
-    }
+  if (const char *e = getenv("CHOLMI_FLOW_NBM")) {  // "lo:hi": tiles of lo .. hi 128-blocks may use the flow form (2 <= lo, hi <= 8)
+    int lo = 0, hi = 0;
+    if (sscanf(e, "%d:%d", &lo, &hi) == 2) cholmi::g_flow_min_nbm = std::max(2, lo), cholmi::g_flow_max_nbm = std::min(8, hi);
   }
+  if (const char *e = getenv("CHOLMI_FLOW_FENCES")) cholmi::g_flow_fences = atoi(e);
+  if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
+  if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
+  HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
+  HIPCHECK(hipMalloc(&g.d_ytab, YTAB_ENTRIES * sizeof(int)));
+  HIPCHECK(hipMemset(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int)));
+  cholmi::g_ytab = g.d_ytab;
   int rc = rank_ctx_create(&g.r, g.r.device, nullptr);
   if (rc) return rc;
   g.inited = true;
@@ -1507,10 +1490,8 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "bench_update before chol_init");
   if (!d || !ms || d->p * d->q != 1 || !d->on_device || d->mt != d->nt || k < 0 || k + 1 >= d->nt || reps < 1)
     return fail(-1, "bench_update: arguments");
-#ifndef CHOLMI_DIAGNOSTICS
-  if (ablate != 0)
-    return fail(CHOL_ERR_NOT_SUPPORTED, "bench_update: the ablation twin of the update is a diagnostic build (make DIAG=1)");
-#endif
+  if (ablate != 0)  // (the ablation twin of the update left the library in round 5; git eb8498c has it)
+    return fail(CHOL_ERR_NOT_SUPPORTED, "bench_update: ablate must be 0");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   int rc = ensure_events(2);
   if (rc) return rc;
@@ -1520,7 +1501,6 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
   pan.base[0] = (char *)d->mat + (size_t)k * d->nt * d->bsizi * d->esize;
   const LocalMat C = local_mat(d, d->mat);
   const ColRange rr = col_range(d, k + 1, d->nt);
-  cholmi::g_ablate = ablate;
   float best = 1e30f;
   for (int r = 0; r <= reps; ++r) {
     HIPCHECK(hipEventRecord(g.r.events[0], g.r.st[ST_MAIN]));
@@ -1534,7 +1514,6 @@ int chol_bench_update(chol_desc_t *d, int k, int ablate, int reps, double *ms, d
     HIPCHECK(hipEventElapsedTime(&t, g.r.events[0], g.r.events[1]));
     if (r > 0 && t < best) best = t;
   }
-  cholmi::g_ablate = 0;
   *ms = best;
   const double ntl = (double)(d->nt - 1 - k);
   if (flops) *flops = (ntl * (ntl - 1) + ntl) * (double)d->mbi * d->mbi * d->mbi;
@@ -1580,10 +1559,7 @@ int chol_debug_update_kernel(int dtype, char *buf, int buflen) {
   const bool f64 = dtype == CHOL_REAL_DOUBLE;
   if (!f64 && dtype != CHOL_REAL_FLOAT) return fail(-1, "debug_update_kernel: dtype");
   // mirrors the dispatch of launch_trail_update (kernels.hip)
-  if (cholmi::g_variant >= 2 && !f64 && cholmi::g_f32_w8) snprintf(buf, buflen, "cholmi::k_trail_update_w8f");
-  else if (cholmi::g_variant >= 2 && f64) snprintf(buf, buflen, "cholmi::k_trail_update_w8<double, %d>", std::min(3, cholmi::g_variant - 2));
-  else if (cholmi::g_variant == 1) snprintf(buf, buflen, "cholmi::k_trail_update<%s, false, false>", f64 ? "double" : "float");
-  else snprintf(buf, buflen, "cholmi::k_trail_update<%s, true, %s>", f64 ? "double" : "float", cholmi::g_late_dma ? "true" : "false");
+  snprintf(buf, buflen, f64 ? "cholmi::k_trail_update_w8<double, 3>" : "cholmi::k_trail_update_w8f");
   return 0;
 }
 
@@ -1591,6 +1567,13 @@ int chol_debug_update_kernel(int dtype, char *buf, int buflen) {
 // out[0..3] = fp64 MFMA probe [TFLOP/s], fp64 diagonal-block step [us], fp32 probe, fp32 step;
 // out[4..7] = the derived per-dtype update rate [TFLOP/s] and panel step [us] the walker uses (walker.h: WaveCalib)
 int chol_debug_flow_waves(void) { return g.r.flow_waves; }
+
+int chol_last_potrf_regimes(int *out8, int *nt) {
+  if (!out8) return fail(-1, "last_potrf_regimes: NULL");
+  for (int i = 0; i < 8; ++i) out8[i] = g.r.regimes[i];
+  if (nt) *nt = g.r.regimes_nt;
+  return 0;
+}
 
 int chol_debug_calibration(double *out8) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "debug_calibration before chol_init");

@@ -47,7 +47,7 @@ enum { ST_MAIN = 0, ST_PANEL, ST_TRSM, ST_U1, ST_CX, ST_PX, ST_COUNT };
 
 constexpr int SEM_SLOTS = 65536;   // device-side counters: 3 mb/128 + 1 per tile column (+ the flow's control block) ...
 constexpr int TILE_SEM_SETS = 8;   // ... plus rotating sets of 32 for the single-tile POTRF's fused in-tile steps
-constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32 + 8) * 32;  // (+ 8: the per-XCD block counters of the persistent update launch)  // ... each on a 128-byte line of its own
+constexpr int SEM_INTS = (SEM_SLOTS + TILE_SEM_SETS * 32) * 32;  // ... each on a 128-byte line of its own
 
 // device buffers that live as long as the context (receive buffers of the distributed walker)
 struct DevPool {
@@ -85,6 +85,8 @@ struct RankCtx {
   double total_ms = 0, update_ms = 0, update_flops = 0, issue_us = 0;
   int update_launches = 0;
   int flow_waves = 0;  // waves of the last whole-matrix potrf whose tile POTRF ran in flow form (kernels.hip: k_flow_factor)
+  int regimes[8] = {};  // ... and its waves per regime (walker.h: Walker::R_*), of regimes_nt waves (chol_last_potrf_regimes)
+  int regimes_nt = 0;
   long long sends = 0, recvs = 0, bytes_sent = 0;
   DevPool pool;
   // measured once at creation, by dtype (0 = f64, 1 = f32): the register-only MFMA stream's rate [TFLOP/s]
@@ -124,27 +126,16 @@ struct LocalMat {
   long bsiz; // elements per tile
 };
 
-extern int g_ablate;
-extern int g_variant;
-extern int g_intile_small;
 extern int g_trsm_small_max;
 extern int g_poll_max_wgs;
 // the flow form of a counter-linked wave's tile POTRF (kernels.hip: k_flow_factor): does it apply to tiles of nbm 128-blocks
 bool flow_applies(int nbm);
-extern int g_persist;
 extern int g_flow;
 extern int g_flow_min_nbm;
 extern int g_flow_max_nbm;
-extern int g_flow_rows;  // 1: eager row slabs (k_flow_rows); 2: streaming (k_flow_rows2); 3: streaming, head tile included; 4: the whole panel (up to g_flow_panel_max tiles)
-extern int g_flow_panel_max;
-void launch_sem_set(hipStream_t s, int *sem);
 extern int g_flow_fences;
 extern int g_intile_fused;
-extern int g_intile_fused_max;
 extern int g_min_units;
-extern int g_trsm_fused_min;
-extern int g_late_dma;
-extern int g_f32_w8;
 extern unsigned long long *g_dbg;
 extern int *g_ytab;
 constexpr int YTAB_ENTRIES = 2048;
@@ -157,8 +148,7 @@ constexpr int YTAB_ENTRIES = 2048;
 // pan2 != null: the updates by two panels in one pass (C -= L L^T of `pan`, then of `pan2`)
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield = false, const PanelRef *pan2 = nullptr,
-                         int *persist_ctr = nullptr);  // persist_ctr: 8 x 32 ints of the stream's own; the launch deals its blocks itself
+                         int nb, const PanelRef &pan, bool yield = false, const PanelRef *pan2 = nullptr);
 
 // In-tile blocked POTRF of one mb x mb tile (device pointer, ld = mb).  Writes the
 // inverses of the MACRO x MACRO diagonal blocks of L to winv (mb/MACRO blocks of
@@ -172,8 +162,7 @@ template <typename T>
 void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb);
 
 // POTRF(tile) on stream sp with the TRSM of `ntiles` contiguous tiles pipelined behind it on
-// stream st (ev: mb/MACRO + 1 events).  ev_head (may be null): recorded once the FIRST panel tile is
-// solved (a long panel's other tiles follow in one throughput-form launch).
+// stream st (ev: mb/MACRO + 1 events).  ev_head (may be null): recorded once the panel is solved.
 // chol_init's probe: the consumer kernel goes first, polls *sem (zeroed) for <= ~20 ms and writes 1 (seen) or
 // 2 (gave up) to *result; the producer kernel raises *sem
 void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int *result);
@@ -197,18 +186,7 @@ struct SyrkPipe {
   int *fc = nullptr;
   hipStream_t sflow = nullptr;
   hipEvent_t ev_flow = nullptr;
-  bool join_flow = false;  // the wave before was not in flow form
-  // column k+1 (not only its diagonal tile) is updated in K = 128 slices behind the panel's steps: the last slice's
-  // workgroups -- n (n + 1) / 2 + (ntiles - 1) n^2, n = mb / 64 -- are what `done` counts
-  bool col_slices = false;
-  // the flow's row-slab launch also solves the rows of the head tile L(k+1,k) (k_flow_rows2); head_ready: the counter
-  // a one-thread launch raises behind that tile's last writer, or null when the flow stream's order covers it
-  bool head_flow = false;
-  const int *head_ready = nullptr;
-  // H[nbm-1] counts the last step's solves of EVERY panel tile: "panel complete" as a counter (what a gate ahead of the
-  // column-(k+1) launch polls instead of waiting for an event); the launcher reports what it counts up to
-  bool panel_done_all = false;
-  mutable int panel_target = 0;
+  bool join_flow = false;  // the flow stream has to join the POTRF stream's order by an event (walker.h)
 };
 inline int flow_ctl_lines(int nbm) { return nbm >= 2 && nbm <= 8 ? 1 + nbm + 2 * nbm * nbm : 0; }
 
@@ -220,7 +198,6 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
 
 template <typename T>
 void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz, int *done);
-void launch_sem_gate(hipStream_t s, const int *sem, int target, int *fail);
 
 // winv from an already factored tile
 template <typename T>

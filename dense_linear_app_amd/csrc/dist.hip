@@ -94,7 +94,7 @@ struct HipOps {
     C.bsiz = desc->bsizi;
   }
   bool profiling() const { return r.profiling; }
-  bool pipe_ok() const { return g_intile_small && g_trsm_fused_min <= 0; }
+  bool pipe_ok() const { return true; }
   bool counters() const { return sem_ok; }
   bool can_split_trsm() const { return true; }
   void *stream(int st) { return r.st[st]; }
@@ -106,10 +106,6 @@ struct HipOps {
   void *flow_event() {
     if (!r.ev_flow) (void)hipEventCreateWithFlags(&r.ev_flow, hipEventDisableTiming);
     return r.ev_flow;
-  }
-  int signal(int st, int *sem) {  // a counter raised in stream order: what a resident kernel of another stream polls
-    launch_sem_set(r.st[st], sem);
-    return launched();
   }
   int launched() {
     const hipError_t e = hipGetLastError();
@@ -154,19 +150,13 @@ struct HipOps {
   }
   int update(int, int, int jlo, int jhi, int what, const PanelRef &p1, const PanelRef *p2, bool yield, int st) {
     const ColRange c = col_range(d, jlo, jhi);
-    // (the counters of the persistent form: behind the library's semaphores, used by ST_MAIN's launches only -- in order)
-    int *pc = (g_persist && st == ST_MAIN && r.d_sem) ? r.d_sem + (size_t)(SEM_SLOTS + TILE_SEM_SETS * 32) * 32 : nullptr;
-    launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2, pc);
+    launch_trail_update<T>(r.st[st], C, d->d_list, c.off, (what & 1) ? c.na : 0, c.offb, (what & 2) ? c.nb : 0, p1, yield, p2);
     return launched();
   }
   // one GPU: column k+1 below its diagonal tile, by panel k, in the latency form (kernels.hip: launch_col_update_small)
-  int update_col_small(int k, int st, int *done) {
+  int update_col_small(int k, int st) {
     launch_col_update_small<T>(r.st[st], (T *)tile(k + 2, k + 1), (const T *)tile(k + 2, k), (const T *)tile(k + 1, k), g.mb,
-                               g.nt - k - 2, (long)g.mb * g.mb, done);
-    return launched();
-  }
-  int gate(int st, const int *sem, int target) {  // the stream goes on when the counter has reached its target
-    launch_sem_gate(r.st[st], sem, target, r.d_info);
+                               g.nt - k - 2, (long)g.mb * g.mb, nullptr);
     return launched();
   }
   // the streams have been joined into ST_MAIN and `ev_stop` recorded there
@@ -217,9 +207,7 @@ struct CbOps {
   int *sem(int, int, int) { return nullptr; }
   bool flow_ok() const { return false; }
   void *flow_event() { return nullptr; }
-  int signal(int, int *) { return 0; }
-  int update_col_small(int, int, int *) { return 0; }
-  int gate(int, const int *, int) { return 0; }
+  int update_col_small(int, int) { return 0; }
   int begin(int, int, int) { return 0; }
   int rec(int, int) { return 0; }
   int wt(int, int) { return 0; }
@@ -506,6 +494,8 @@ int walk_t(chol_desc *d, void *base, RankCtx *r, int rank, WaveComm *cm, bool re
   r->update_flops = w.upd_flops;
   r->update_launches = w.upd_launches;
   r->flow_waves = w.flow_waves;
+  for (int i = 0; i < 8; ++i) r->regimes[i] = i < Walker<HipOps<T>>::R_COUNT ? w.regimes[i] : 0;
+  r->regimes_nt = g.nt;
   r->issue_us = w.issue_us / (g.nt > 0 ? g.nt : 1);  // per wave
   r->sends = cm ? cm->nsend : 0, r->recvs = cm ? cm->nrecv : 0, r->bytes_sent = cm ? cm->bytes_sent : 0;
   if (rc) return rc;

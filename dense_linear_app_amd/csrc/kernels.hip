@@ -18,8 +18,8 @@
 //     contiguous per 16 lanes (col-major C);
 //   - double-buffered LDS (64 KiB per workgroup), one barrier per K-slice; 2 workgroups per CU
 //     (<= 232 VGPR) hide the C epilogue behind the other workgroup's MFMA stream.
-// nt_kloop (register-staged, row stride 144) is the first version: it carries the operand masks
-// the residual kernel needs and the ablation switches of the diagnostic twin of the update.
+// nt_kloop (register-staged, row stride 144) serves the residual kernel only: it carries the operand
+// masks that kernel needs (tril of the diagonal tiles).
 #include "cholmi_internal.h"
 
 #include <type_traits>
@@ -92,7 +92,7 @@ __device__ __forceinline__ void acc_zero(Acc<T> &acc) {
 template <typename T, bool MASKA, bool MASKB>
 __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const T *__restrict__ B,
                                          int ldb, int K, Acc<T> &acc, Smem<T> &sm, int amask,
-                                         int bmask, int ablate = 0) {
+                                         int bmask) {
   using vec_t = typename Tr<T>::vec_t;
   constexpr int EPV = Tr<T>::EPV;
   constexpr int TPC = MACRO / EPV;  // threads per k-column
@@ -134,17 +134,15 @@ __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk && !(ablate & 1)) gload((ablate & 32) ? 0 : (kt + 1) * BK);  // 32: cache-hot loads
+    if (kt + 1 < nk) gload((kt + 1) * BK);
     T af[4], bf[4];
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       const int kk = ks * 4 + (lane >> 4);
-      if (!(ablate & 2) || (kt == 0 && ks == 0)) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) af[a] = sm.a[cur][kk][wr * 64 + a * 16 + (lane & 15)];
+      for (int a = 0; a < 4; ++a) af[a] = sm.a[cur][kk][wr * 64 + a * 16 + (lane & 15)];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bf[b] = sm.b[cur][kk][wc * 64 + b * 16 + (lane & 15)];
-      }
+      for (int b = 0; b < 4; ++b) bf[b] = sm.b[cur][kk][wc * 64 + b * 16 + (lane & 15)];
       // stage the next slice into the other LDS buffer under the last MFMA group, so
       // that nothing but the barrier itself is left at the end of the slice
       if (ks == BK / 4 - 1 && kt + 1 < nk) lstore(cur ^ 1);
@@ -153,7 +151,7 @@ __device__ __forceinline__ void nt_kloop(const T *__restrict__ A, int lda, const
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = Tr<T>::mfma(bf[b], af[a], acc[a][b]);
     }
-    if (!(ablate & 8)) __syncthreads();
+    __syncthreads();
   }
 }
 
@@ -319,61 +317,34 @@ struct alignas(16) SmemP {
   T b[2][BK][MACRO];
 };
 
-template <typename T, bool DMA, bool LATE = false>
+template <typename T>
 __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda,
                                                 const T *__restrict__ B, int ldb, int K, Acc<T> &acc,
                                                 SmemP<T> &sm, const int *yslot = nullptr) {
   using vec_t = typename Tr<T>::vec_t;
   constexpr int EPV = Tr<T>::EPV;  // elements per 16 bytes == EPL
   constexpr int NG = 4 / EPV;      // 16-lane row groups per 64 rows: fp64 2, fp32 1
-  constexpr int TPC = MACRO / EPV;
-  constexpr int CPP = 256 / TPC;
-  constexpr int NP = BK / CPP;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
-  const int lrow = (t % TPC) * EPV, lcol = t / TPC;
-  vec_t ra[NP], rb[NP];
-  const T *Ag = A + lrow + (size_t)lcol * lda;
-  const T *Bg = B + lrow + (size_t)lcol * ldb;
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      ra[p] = *reinterpret_cast<const vec_t *>(Ag + (size_t)(k0 + p * CPP) * lda);
-      rb[p] = *reinterpret_cast<const vec_t *>(Bg + (size_t)(k0 + p * CPP) * ldb);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      *reinterpret_cast<vec_t *>(&sm.a[buf][p * CPP + lcol][lrow]) = ra[p];
-      *reinterpret_cast<vec_t *>(&sm.b[buf][p * CPP + lcol][lrow]) = rb[p];
-    }
-  };
   // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction moves one 1 KiB piece
   // (64 lanes x 16 B) straight into the LDS image at a wave-uniform base -- no staging
   // registers, no ds_write.  Piece q of a slice = bytes [q KiB, (q+1) KiB) of the
   // [BK][128] image; wave w moves pieces w, w+4, ...
   constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024;  // per operand per slice
   constexpr int EPP = 1024 / (int)sizeof(T);                  // elements per piece
-  auto dma_piece = [&](int buf, int k0, int q) {
-    const int piece = q * 4 + w;
-    const int e = piece * EPP + lane * EPV;  // element index inside the slice image
-    const int kk = e / MACRO, r = e % MACRO;
-    T *la = &sm.a[buf][0][0] + piece * EPP;
-    T *lb = &sm.b[buf][0][0] + piece * EPP;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
-        (__attribute__((address_space(3))) void *)la, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
-        (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
-  };
   auto dma = [&](int buf, int k0) {
 #pragma unroll
-    for (int q = 0; q < PIECES / 4; ++q) dma_piece(buf, k0, q);
+    for (int q = 0; q < PIECES / 4; ++q) {
+      const int piece = q * 4 + w;
+      const int e = piece * EPP + lane * EPV;  // element index inside the slice image
+      const int kk = e / MACRO, r = e % MACRO;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(A + r + (size_t)(k0 + kk) * lda),
+          (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(B + r + (size_t)(k0 + kk) * ldb),
+          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
+    }
   };
-  // LATE: the next slice's DMA goes out behind the first MFMA of k-groups 0 and 1 instead of in one
-  // burst between the barrier and the slice's first MFMA (kernels.hip: nt_kloop_w8, MODE bit 0)
-  constexpr int PPG = PIECES / 4 / 2;  // pieces per operand, wave and early k-group
   vec_t fa[2][NG], fb[2][NG];
   const int arow = wr * 64 + EPV * (lane & 15), brow = wc * 64 + EPV * (lane & 15), kq = lane >> 4;
   auto fread = [&](int set, int cur, int ks) {
@@ -384,12 +355,7 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
     }
   };
 
-  if (DMA) {
-    dma(0, 0);
-  } else {
-    gload(0);
-    lstore(0);
-  }
+  dma(0, 0);
   __syncthreads();
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
@@ -397,13 +363,7 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
     int guest = 0;  // requested ahead of the DMA, looked at after the slice's MFMAs
     if (yslot) guest = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fread(0, cur, 0);
-    if (kt + 1 < nk) {
-      if (DMA) {
-        if (!LATE) dma(cur ^ 1, (kt + 1) * BK);
-      } else {
-        gload((kt + 1) * BK);
-      }
-    }
+    if (kt + 1 < nk) dma(cur ^ 1, (kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       // The group's own fragments were requested a whole group (1024 cycles) ago, so the
@@ -413,14 +373,7 @@ __device__ __forceinline__ void nt_kloop_paired(const T *__restrict__ A, int lda
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = Tr<T>::mfma(fb[ks & 1][0][0], fa[ks & 1][0][0], acc[0][0]);
       __builtin_amdgcn_sched_barrier(0);
-      if (DMA && LATE && ks < 2 && kt + 1 < nk) {
-#pragma unroll
-        for (int q = 0; q < PPG; ++q) dma_piece(cur ^ 1, (kt + 1) * BK, ks * PPG + q);
-      }
-      if (ks + 1 < BK / 4)
-        fread((ks + 1) & 1, cur, ks + 1);
-      else if (!DMA && kt + 1 < nk)
-        lstore(cur ^ 1);
+      if (ks + 1 < BK / 4) fread((ks + 1) & 1, cur, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -479,66 +432,6 @@ __device__ __forceinline__ void nt_epilogue_paired_impl(T *__restrict__ C, int l
       }
     }
   }
-}
-
-// C(128x128 block) := alpha*acc + beta*C ; LOWER: store only elements with m >= n
-// (diagonal blocks of SYRK-type updates).  The C tile is read in four batches of 16
-// loads per lane (all issued before the first use), then written: four memory round
-// trips per workgroup instead of one per element.
-template <typename T, bool LOWER>
-__device__ __forceinline__ void nt_epilogue_impl(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
-                                                 T beta) {
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1;
-  const int m0 = wr * 64 + (lane & 15);
-  if (beta == T(0)) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
-        T *col = C + (size_t)n * ldc;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int m = m0 + a * 16;
-          if (!LOWER || m >= n) col[m] = alpha * acc[a][b][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    T cv[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
-      const T *col = C + (size_t)n * ldc;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cv[r][a] = col[m0 + a * 16];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cv[r][a] = alpha * acc[a][b][r] + beta * cv[r][a];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = wc * 64 + b * 16 + Tr<T>::drow(lane, r);
-      T *col = C + (size_t)n * ldc;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int m = m0 + a * 16;
-        if (!LOWER || m >= n) col[m] = cv[r][a];
-      }
-    }
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void nt_epilogue(T *__restrict__ C, int ldc, Acc<T> &acc, T alpha,
-                                            T beta, bool lower, int, int) {
-  if (lower)
-    nt_epilogue_impl<T, true>(C, ldc, acc, alpha, beta);
-  else
-    nt_epilogue_impl<T, false>(C, ldc, acc, alpha, beta);
 }
 
 template <typename T>
@@ -609,8 +502,7 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
     out.ij = list[t];
     out.mi = macro % nbm;
     out.mj = macro / nbm;
-    // (a diagonal tile in segment A only in the diagnostic interleaved order, CHOLMI_LIST_ORDER)
-    return !(out.ij.x == out.ij.y && out.mi < out.mj);
+    return true;
   }
   b -= blocks_a;
   const int MTd = nbm * (nbm + 1) / 2;
@@ -630,59 +522,6 @@ __device__ __forceinline__ bool map_update_block(const int2 *__restrict__ list, 
   out.mj = mj;
   out.mi = mj + macro;
   return true;
-}
-
-#ifdef CHOLMI_DIAGNOSTICS  // diagnostic twin of the update (register staging, ablation switches): make DIAG=1
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_trail_update_diag(LocalMat C, const int2 *__restrict__ list,
-                                                         int na, int offb, int nb, int blocks_a, PanelRef pan,
-                                                         int nbm, int unit, int ablate) {
-  __shared__ Smem<T> sm;
-  BlockMap bm;
-  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
-  const int2 ij = bm.ij;
-  const int mi = bm.mi, mj = bm.mj;
-  const bool diag = (ij.x == ij.y);
-  const T *Ap = panel_tile<T>(pan, ij.x, C.bsiz) + mi * MACRO;
-  const T *Bp = panel_tile<T>(pan, ij.y, C.bsiz) + mj * MACRO;
-  T *Cp = reinterpret_cast<T *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
-          mi * MACRO + (long)mj * MACRO * C.mb;
-  Acc<T> acc;
-  acc_zero<T>(acc);
-  nt_kloop<T, false, false>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, 0, 0, ablate);
-  nt_epilogue<T>(Cp, C.mb, acc, T(-1), (ablate & 4) ? T(0) : T(1), diag && mi == mj, 0, 0);
-}
-#endif
-
-// npan = 2: the updates by two consecutive panels in one pass, C(i,j) -= L(i,k-1) L(j,k-1)^T +
-// L(i,k) L(j,k)^T -- one K-loop of twice the length per C block (the walker defers the far columns'
-// update by the even panel of a pair): half the C traffic, prologues and epilogues per flop.
-template <typename T, bool DMA, bool LATE = false>
-__global__ __launch_bounds__(256, 2) void k_trail_update(LocalMat C, const int2 *__restrict__ list,
-                                                           int na, int offb, int nb, int blocks_a, PanelRef pan,
-                                                           int nbm, int unit, const int *ytab, PanelRef pan2,
-                                                           int npan) {
-  __shared__ SmemP<T> sm;
-  BlockMap bm;
-  if (!map_update_block(list, na, offb, nb, nbm, blocks_a, unit, bm)) return;
-  const int2 ij = bm.ij;
-  const int mi = bm.mi, mj = bm.mj;
-  const bool diag = (ij.x == ij.y);
-  const T *Ap = panel_tile<T>(pan, ij.x, C.bsiz) + mi * MACRO;
-  const T *Bp = panel_tile<T>(pan, ij.y, C.bsiz) + mj * MACRO;
-  T *Cp = reinterpret_cast<T *>(C.base) + ((long)(ij.x / C.P) + (long)(ij.y / C.Q) * C.lmt) * C.bsiz +
-          mi * MACRO + (long)mj * MACRO * C.mb;
-  Acc<T> acc;
-  acc_zero<T>(acc);
-  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
-  nt_kloop_paired<T, DMA, LATE>(Ap, C.mb, Bp, C.mb, C.mb, acc, sm, yslot);
-  if (npan > 1)
-    nt_kloop_paired<T, DMA, LATE>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
-                            panel_tile<T>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
-  if (diag && mi == mj)
-    nt_epilogue_paired_impl<T, true>(Cp, C.mb, acc, T(-1), T(1));
-  else
-    nt_epilogue_paired_impl<T, false>(Cp, C.mb, acc, T(-1), T(1));
 }
 
 // ------------------------------------------------------------------------------
@@ -822,28 +661,6 @@ __global__ __launch_bounds__(512, 4) void k_trail_update_w8(LocalMat C, const in
   trail_update_w8_block<T, MODE>(C, list, na, offb, nb, blocks_a, pan, nbm, unit, ytab, pan2, npan, sm, (int)blockIdx.x);
 }
 
-// The same update with a grid of the chip's resident slots (two workgroups per CU) whose workgroups deal themselves
-// the blocks: one counter per XCD (blockIdx & 7, as the static map assumes), a workgroup on XCD x takes the blocks
-// x, x + 8, x + 16, ... of the static numbering in turn, so the L2 locality of the unit scheme is kept.  Experiment of
-// round 4 (CHOLMI_PERSIST=1, the far launch only): what a launch of 4-16 rounds pays per round is dispatch, not work.
-template <typename T, int MODE>
-__global__ __launch_bounds__(512, 4) void k_trail_update_w8p(LocalMat C, const int2 *__restrict__ list, int na,
-                                                              int offb, int nb, int blocks_a, PanelRef pan, int nbm,
-                                                              int unit, const int *ytab, PanelRef pan2, int npan,
-                                                              int *ctr, int total) {
-  __shared__ SmemP<T> sm;
-  __shared__ int next_s;
-  const int x = blockIdx.x & 7;
-  for (;;) {
-    if (threadIdx.x == 0) next_s = __hip_atomic_fetch_add(ctr + 32 * x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int b = 8 * next_s + x;
-    __syncthreads();
-    if (b >= total) break;
-    trail_update_w8_block<T, MODE>(C, list, na, offb, nb, blocks_a, pan, nbm, unit, ytab, pan2, npan, sm, b);
-  }
-}
-
 // ------------------------------------------------------------------------------
 // fp32 trailing update on eight waves with K-slices of 32.  The fp32 16x16x4 MFMA issues every 32
 // cycles (twice the fp64 rate), so with 16-deep slices a wave meets a barrier after 2048 cycles of
@@ -974,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
                                                         int s, const T *__restrict__ winv, T alpha,
                                                         int *ytab, const int *wait_sem = nullptr,
                                                         int wait_target = 0, int *fail = nullptr,
-                                                        int *head_sem = nullptr, int count_all = 0) {
+                                                        int *head_sem = nullptr) {
   __shared__ SmemP<T> sm;
   sem_wait(wait_sem, wait_target, fail);
   GuestOnCu guest(ytab);
@@ -985,10 +802,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_solve(T *tiles, long bsiz, int
   const T *Bp = winv + (long)s * MACRO * MACRO;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, true>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
+  nt_kloop_paired<T>(Ap, mb, Bp, MACRO, MACRO, acc, sm);
   nt_epilogue_paired<T>(Ap, mb, acc, alpha, T(0), false);
   guest.leave();
-  if (tix == 0 || count_all) sem_signal(head_sem);  // (the first tile's workgroups: nr counts -- or every tile's)
+  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: nr counts)
 }
 
 // A[:, c] := beta*A[:, c] - X[:, s] * L[c, s]^T for c > s (right-looking TRSM step)
@@ -1012,208 +829,8 @@ __global__ __launch_bounds__(256, 2) void k_panel_update(T *tiles, long bsiz, in
   T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
+  nt_kloop_paired<T>(Ap, mb, Bp, mb, MACRO, acc, sm);
   nt_epilogue_paired<T>(Cp, mb, acc, T(-1), beta, false);
-  guest.leave();
-}
-
-// ------------------------------------------------------------------------------
-// Panel TRSM, throughput form (fp64):  X(i,k) = A(i,k) L(k,k)^{-T}  for many tiles in ONE launch, in
-// place.  One workgroup per 128-row block of a tile, left-looking over the 128-column blocks c:
-//     X[:,c] = (A[:,c] - sum_{s<c} X[:,s] L(c,s)^T) Winv_c^T
-// -- the arithmetic of the stepwise form (k_panel_solve + k_panel_update: products with the inverted
-// 128 x 128 diagonal blocks), but the sum over s is ONE K-loop of length 128 c (X[:,0:128c] and
-// L(c,0:128c) are contiguous column ranges), nothing is read-modify-written per step, and a wave of
-// the DAG needs one launch instead of 2 nbm.  The stepwise form moves every block of the tile
-// through HBM/L2 once per step (16 flop/B) and runs at 25-50 % MFMA utilisation, which is what the
-// trailing update loses when the two share the chip.
-// Wave w owns rows 32w..32w+31 and ALL 128 columns of the block, so that the second product needs
-// no LDS round trip: with the operands passed swapped, lane (i, q) holds in accumulator register r of
-// tile (a, b) the element (row 32w + 2i + a, column n = 32(b>>1) + 8r + 2q + (b&1)) -- exactly the
-// value the 16x16x4 MFMA wants from it as the k = n operand of the next product, T Winv^T.
-// The second product runs in two passes of 64 output columns (accumulators: 128 + 64 VGPRs).
-// ------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_trsm_fused(T *tiles, long bsiz, int mb, int nbm,
-                                                       const T *__restrict__ lkk, const T *__restrict__ winv) {
-  static_assert(sizeof(T) == 8, "fp64 only: the fp32 fragment pairing covers 64 rows");
-  using vec_t = typename Tr<T>::vec_t;
-  using acc_t = typename Tr<T>::acc_t;
-  __shared__ SmemP<T> sm;
-  const int tix = blockIdx.x / nbm, rb = blockIdx.x % nbm;
-  T *Arow = tiles + (long)tix * bsiz + rb * MACRO;  // element (m, n) of the row block at Arow[m + n * mb]
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i = lane & 15, q = lane >> 4;
-  constexpr int PIECES = BK * MACRO * (int)sizeof(T) / 1024;  // 1 KiB pieces per operand per K-slice
-  constexpr int EPP = 1024 / (int)sizeof(T);
-  // both operands of a slice: A = rows of this block, columns k0..k0+15; B = rows of Bsrc, same columns
-  auto dma2 = [&](int buf, const T *Asrc, int lda, const T *Bsrc, int ldb, int k0) {
-#pragma unroll
-    for (int p = 0; p < PIECES / 4; ++p) {
-      const int piece = p * 4 + w;
-      const int e = piece * EPP + lane * 2;
-      const int kk = e / MACRO, r = e % MACRO;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(Asrc + r + (size_t)(k0 + kk) * lda),
-          (__attribute__((address_space(3))) void *)(&sm.a[buf][0][0] + piece * EPP), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(Bsrc + r + (size_t)(k0 + kk) * ldb),
-          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
-    }
-  };
-  auto dma1 = [&](int buf, const T *Bsrc, int ldb, int k0) {
-#pragma unroll
-    for (int p = 0; p < PIECES / 4; ++p) {
-      const int piece = p * 4 + w;
-      const int e = piece * EPP + lane * 2;
-      const int kk = e / MACRO, r = e % MACRO;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(Bsrc + r + (size_t)(k0 + kk) * ldb),
-          (__attribute__((address_space(3))) void *)(&sm.b[buf][0][0] + piece * EPP), 16, 0, 0);
-    }
-  };
-  const int arow = 32 * w + 2 * i;
-  for (int c = 0; c < nbm; ++c) {
-    acc_t acc[2][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 8; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
-    // ---- S = X[:, 0:128c] L(c, 0:128c)^T
-    if (c > 0) {
-      const T *Bsrc = lkk + c * MACRO;
-      const int nk = c * (MACRO / BK);
-      vec_t fa[2], fb[2][4];
-      auto fread = [&](int set, int cur, int ks) {
-        fa[set] = *reinterpret_cast<const vec_t *>(&sm.a[cur][ks * 4 + q][arow]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) fb[set][g] = *reinterpret_cast<const vec_t *>(&sm.b[cur][ks * 4 + q][32 * g + 2 * i]);
-      };
-      dma2(0, Arow, mb, Bsrc, mb, 0);
-      __syncthreads();
-      for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        fread(0, cur, 0);
-        if (kt + 1 < nk) dma2(cur ^ 1, Arow, mb, Bsrc, mb, (kt + 1) * BK);
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-          __builtin_amdgcn_sched_barrier(0);
-          acc[0][0] = Tr<T>::mfma(fb[ks & 1][0][0], fa[ks & 1][0], acc[0][0]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (ks + 1 < BK / 4) fread((ks + 1) & 1, cur, ks + 1);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-              if (a + b > 0) acc[a][b] = Tr<T>::mfma(fb[ks & 1][b >> 1][b & 1], fa[ks & 1][a], acc[a][b]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-      }
-    }
-    // ---- T = A[:, c] - S, in the accumulator layout (two consecutive rows per 16-byte load)
-    // lane ids made opaque per column block: otherwise the 64 per-lane addresses of the loads and
-    // stores below are hoisted out of the c loop (they are loop-invariant up to the block offset), kept
-    // for its whole length and spill the accumulators
-    int q_ = q, i_ = i;
-    asm volatile("" : "+v"(q_), "+v"(i_));
-    const int arow_ = 32 * w + 2 * i_;
-    T *Cb = Arow + (long)c * MACRO * mb;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      vec_t av[2][4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          av[e][r] = *reinterpret_cast<const vec_t *>(Cb + arow_ + (long)(32 * g + 8 * r + 2 * q_ + e) * mb);
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int a = 0; a < 2; ++a) acc[a][2 * g + e][r] = av[e][r][a] - acc[a][2 * g + e][r];
-      __builtin_amdgcn_sched_barrier(0);  // one batch of 8 loads in flight: all 32 hoisted together spill the accumulators
-    }
-    // ---- X[:, c] = T Winv_c^T: the operand T comes straight from the accumulator registers
-    const T *Wc = winv + (long)c * MACRO * MACRO;  // column-major, ld = 128: column k = the k-th row of the [k][n'] image
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      acc_t y[2][4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) y[a][b][r] = T(0);
-      dma1(0, Wc, MACRO, 0);
-      __syncthreads();
-      static_for<0, MACRO / BK>([&](auto S) {
-        constexpr int s = decltype(S)::value, cur = s & 1, g = s >> 1;
-        if constexpr (s + 1 < MACRO / BK) dma1(cur ^ 1, Wc, MACRO, (s + 1) * BK);
-        // the four k-groups of the slice: (r, e), lane (i, q) contributes k = 16 s + 8 (r & 1) + 2 q + e;
-        // W fragments double-buffered one k-group ahead, nothing hoisted across the groups
-        vec_t fw[2][2];
-        auto wread = [&](int set, int st) {
-#pragma unroll
-          for (int gg = 0; gg < 2; ++gg)
-            fw[set][gg] = *reinterpret_cast<const vec_t *>(&sm.b[cur][8 * (st >> 1) + 2 * q_ + (st & 1)][64 * h + 32 * gg + 2 * i_]);
-        };
-        wread(0, 0);
-        static_for<0, 4>([&](auto ST) {
-          // every index into the accumulator arrays is a compile-time constant (a run-time index
-          // would put them in scratch)
-          constexpr int st = decltype(ST)::value, r = 2 * (s & 1) + (st >> 1), e = st & 1, bt = 2 * g + e;
-          __builtin_amdgcn_sched_barrier(0);
-          y[0][0] = Tr<T>::mfma(fw[st & 1][0][0], acc[0][bt][r], y[0][0]);
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (st + 1 < 4) wread((st + 1) & 1, st + 1);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              if (a + b > 0) y[a][b] = Tr<T>::mfma(fw[st & 1][b >> 1][b & 1], acc[a][bt][r], y[a][b]);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        __syncthreads();
-      });
-      // store the 64 columns of this pass (rows 2i, 2i+1 in one 16-byte store)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          vec_t v;
-          v[0] = y[0][b][r];
-          v[1] = y[1][b][r];
-          *reinterpret_cast<vec_t *>(Cb + arow_ + (long)(64 * h + 32 * (b >> 1) + 8 * r + 2 * q_ + (b & 1)) * mb) = v;
-        }
-    }
-    // the block just written is an operand of the next column block's K-loop (this workgroup's own
-    // LDS-DMA reads): workgroup-scope release / acquire around a barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-}
-
-// in-tile trailing update of the blocked POTRF: C[r,c] -= X[r,s] X[c,s]^T, r >= c > s
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_intile_update(T *tile, int mb, int nbm, int s, int *ytab) {
-  __shared__ SmemP<T> sm;
-  __builtin_amdgcn_s_setprio(2);  // panel chain: ahead of co-resident trailing-update waves
-  const int r = s + 1 + blockIdx.x, c = s + 1 + blockIdx.y;
-  if (c > r) return;
-  GuestOnCu guest(ytab);
-  const T *Ap = tile + r * MACRO + (long)s * MACRO * mb;
-  const T *Bp = tile + c * MACRO + (long)s * MACRO * mb;
-  T *Cp = tile + r * MACRO + (long)c * MACRO * mb;
-  Acc<T> acc;
-  acc_zero<T>(acc);
-  nt_kloop_paired<T, true>(Ap, mb, Bp, mb, MACRO, acc, sm);
-  nt_epilogue_paired<T>(Cp, mb, acc, T(-1), T(1), r == c);
   guest.leave();
 }
 
@@ -1277,7 +894,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int mb, int nbm, int r0, int s,
                                                         const T *__restrict__ winv, T alpha, int *ytab,
                                                         const int *wait_sem = nullptr, int wait_target = 0,
-                                                        int *fail = nullptr, int *head_sem = nullptr, int count_all = 0) {
+                                                        int *fail = nullptr, int *head_sem = nullptr) {
   __shared__ SmallImg<T, 32> ia;
   __shared__ SmallImg<T, MACRO> ib;
   sem_wait(wait_sem, wait_target, fail);
@@ -1317,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void k_solve_small(T *tiles, long bsiz, int
       for (int r = 0; r < 4; ++r)
         Ap[16 * a + lo + (long)(32 * w + 16 * b + Tr<T>::drow(lane, r)) * mb] = alpha * acc[a][b][r];
   guest.leave();
-  if (tix == 0 || count_all) sem_signal(head_sem);  // (the first tile's workgroups: per_tile counts -- or every tile's)
+  if (tix == 0) sem_signal(head_sem);  // (the first tile's workgroups: per_tile counts)
 }
 
 // C(r64, c64) -= A(r64, :) B(c64, :)^T over K columns, for the 64 x 64 blocks on or below the
@@ -1521,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A
   }
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, true>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
+  nt_kloop_paired<T>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
   nt_epilogue_paired<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta,
                  lower && mi == mj);
 }
@@ -1540,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_ptrs(const T *const *__restr
   T *C = Cp[blockIdx.z];
   Acc<T> acc;
   acc_zero<T>(acc);
-  nt_kloop_paired<T, true>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
+  nt_kloop_paired<T>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
   nt_epilogue_paired<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta, lower && mi == mj);
 }
 // dst[z] <- src[z], `bytes` (a multiple of 16) each: the private copies the worker makes of the tiles it updates
@@ -2624,229 +2241,6 @@ __global__ __launch_bounds__(256) void k_flow_rows(T *tile, int mb, int nbm, con
   if (blockIdx.x == 0) dbg_mark(dbg, 1, rb, t_in);
 }
 
-// ---- the streaming form of the row slabs (round 4, second version) -------------------------------------------
-// Every product of the tile POTRF's trailing update is taken ONE PANEL BEHIND the solve instead of after the step:
-// while the wave waits for panel p of L_s it already holds X_{p-1} of its rows, and the rows c' > s of the
-// diagonal tile publish their X(c', s) panel by panel, so  A(r, c') -= X_{p-1}(r) X_{p-1}(c')^T  needs nothing that
-// is not there -- its 32 operand loads fly beside the solve's, and when the step's last panel is solved one rank-16
-// product per block is left (the eager form left 8, 20-35 us of exposed load latency per block).  The blocks
-// (r, s+1), (r, s+2) live in accumulators for the whole tile POTRF -- at the end of step s the first becomes the
-// solve's right-hand side, nothing is written back and read again; a third block ahead (head rows of a 4-block
-// tile, step 0 only) lives in the wave's own 16 KiB of LDS.  Hence tiles of at most 4 blocks.
-// HEAD rows: the rows of the panel's first tile L(k+1,k) -- block row `nbm` of a column two tiles tall -- are
-// solved by this launch as well (mb / 64 more workgroups): they raise H[s], which the K = 128 slices of the SYRK
-// on tile (k+1,k+1) poll, ~3 us after the diagonal block's last panel instead of behind its 128 x 128 inverse,
-// the counter D[s] and a solve launch.  The tile's earlier writer (the update of column k by panel k-1, on ST_U1)
-// is a counter too (head_ready, raised by a one-thread launch behind it; null: stream order covers it).
-template <typename T>
-struct FlowRowsLds {
-  T acc[4][8 * 4 * 64];
-};
-// one round trip for up to four counters: lane i < 4 polls c[i] (null: nothing to wait for) for t[i], lane 4 the
-// abort word; false: aborted or gave up
-__device__ __forceinline__ bool flow_wait4(const int *c0, int t0, const int *c1, const int *c2, const int *c3, int *fc, int *info,
-                                           int fences) {
-  const int lane = threadIdx.x & 63;
-  const int *my = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : lane == 3 ? c3 : lane == 4 ? fc : nullptr;
-  const int tg = lane == 0 ? t0 : 8;
-  bool ok = false;
-  int i = 0;
-  for (; i < FLOW_SPIN; ++i) {
-    const int v = my ? __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    const bool aborted = lane == 4 && v != 0, waiting = lane < 4 && my && v < tg;
-    if (__ballot(aborted) != 0ull) break;
-    if (__ballot(waiting) == 0ull) {
-      ok = true;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(FLOW_POLL_SLEEP);
-  }
-  if (i == FLOW_SPIN && lane == 0) {
-    atomicExch(info, 0x7ffffffe);
-    __hip_atomic_store(fc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (fences) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  asm volatile("" ::: "memory");
-  return ok;
-}
-// panel p of block (c, s) of the diagonal tile as MFMA fragments: lf[j][r] = X[16 j + lo][16 p + drow(lane, r)]
-template <typename T>
-__device__ __forceinline__ void flow_xload(T (&lf)[8][4], const T *tile, int mb, int c, int s, int p, int lo, const size_t (&dcol)[4]) {
-  const T *Xc = tile + (size_t)(MACRO * c + lo) + (size_t)(MACRO * s + 16 * p) * mb;
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lf[j][r] = load_sc1(Xc + 16 * j + dcol[r]);
-}
-template <typename T>
-__device__ __forceinline__ void flow_xmma(typename Tr<T>::acc_t (&acc)[8], const T (&lf)[8][4], const typename Tr<T>::acc_t &nx) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[j] = Tr<T>::mfma(lf[j][r], nx[r], acc[j]);
-}
-template <typename T>
-__device__ __forceinline__ void flow_xmma_lds(T *my, const T (&lf)[8][4], const typename Tr<T>::acc_t &nx) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    typename Tr<T>::acc_t t;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = my[(j * 4 + r) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t = Tr<T>::mfma(lf[j][r], nx[r], t);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) my[(j * 4 + r) * 64 + lane] = t[r];
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_flow_rows2(T *tile, T *head, long bsiz, int mb, int nbm, const T *winv, int *info, int *fc, int *ytab,
-                                                  const int *wait_sem, int wait_target, const int *head_ready, int *isem,
-                                                  int *hsem, int count_all, int fences, unsigned long long *dbg) {
-  using acc_t = typename Tr<T>::acc_t;
-  __shared__ FlowRowsLds<T> lds;
-  const unsigned long long t_in = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  sem_wait(wait_sem, wait_target, info);
-  GuestOnCu guest(ytab);
-  __builtin_amdgcn_s_setprio(2);
-  const int lane = threadIdx.x & 63, lo = lane & 15;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nin = (mb - MACRO) / 64;  // workgroups of the diagonal tile's own rows; then the head tile's
-  const bool is_head = (int)blockIdx.x >= nin;
-  const int hb = (int)blockIdx.x - nin, n64 = mb / 64;
-  const int ptile = is_head ? hb / n64 : 0;  // which tile of the panel (0: the head tile, whose steps H[s] counts)
-  const int R0 = is_head ? 64 * (hb % n64) + 16 * w : MACRO + 64 * (int)blockIdx.x + 16 * w;
-  const int rb = is_head ? nbm : R0 >> 7;  // block row: what the slab has to the left of its diagonal block
-  T *base = is_head ? head + (size_t)ptile * bsiz : tile;
-  size_t dcol[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) dcol[r] = (size_t)Tr<T>::drow(lane, r) * mb;
-  T *mylds = lds.acc[w];
-  bool live = true;
-  if (is_head && head_ready) live = flow_wait(head_ready, 1, fc, info, 1);  // (an acquire: that launch stored normally)
-  acc_t a[8], acc0[8], acc1[8];
-  auto load_blk = [&](acc_t(&d)[8], int c) {
-    const T *B = base + (size_t)(R0 + lo) + (size_t)(MACRO * c) * mb;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d[j][r] = B[(size_t)(16 * j) * mb + dcol[r]];
-  };
-  if (live) {
-    load_blk(a, 0);
-    if (rb > 1) load_blk(acc0, 1);
-    if (rb > 2) load_blk(acc1, 2);
-    if (rb > 3) {
-      const T *B = base + (size_t)(R0 + lo) + (size_t)(MACRO * 3) * mb;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mylds[(j * 4 + r) * 64 + lane] = B[(size_t)(16 * j) * mb + dcol[r]];
-    }
-  }
-  int signalled = 0;  // steps whose counter (I[s], or H[s] for head rows) this wave has raised
-  int *stepsem = is_head ? hsem : isem;
-  for (int s = 0; s < rb && live; ++s) {
-    const int nb = rb - 1 - s;                                        // blocks (rb, s+1 .. s+nb) take this step's products
-    T *Ab = base + (size_t)(R0 + lo) + (size_t)(MACRO * s) * mb;      // my rows of block (rb, s)
-    const T *Ws = winv + (size_t)s * MACRO * MACRO + lo;              // + (16 p) (1 + 128) + drow x 128
-    const T *Ls = tile + (size_t)s * MACRO * (mb + 1) + lo;           // diagonal block s: + 16 c + (16 p) mb + dcol
-    const int *fpan = fc + 32 * (1 + s);
-    const int *hq = fc + 32 * (1 + nbm + s);                          // + 32 nbm c': panels of X(c', s) published
-    int *hp = fc + 32 * (1 + nbm + rb * nbm + s);                     // mine (not for head rows: nobody reads them here)
-    const bool critical = !is_head && rb == s + 1;  // block row s+1: the next diagonal block waits for these panels one by one
-    const unsigned long long t_step = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    acc_t nprev;
-    static_for<0, 9>([&](auto P) {
-      constexpr int p = decltype(P)::value;
-      if (!live) return;
-      if constexpr (p == 8) {
-        if (nb == 0) return;
-      }
-      live = flow_wait4(p < 8 ? fpan : nullptr, p + 1, p > 0 && nb > 0 ? hq + 32 * nbm * (s + 1) + (p - 1) : nullptr,
-                        p > 0 && nb > 1 ? hq + 32 * nbm * (s + 2) + (p - 1) : nullptr,
-                        p > 0 && nb > 2 ? hq + 32 * nbm * (s + 3) + (p - 1) : nullptr, fc, info, fences);
-      if (!live) return;
-      T wd[4], lfL[8][4], lf0[8][4], lf1[8][4];
-      if constexpr (p < 8) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wd[r] = load_sc1(Ws + (size_t)(16 * p) * (MACRO + 1) + (size_t)Tr<T>::drow(lane, r) * MACRO);
-#pragma unroll
-        for (int c = p + 1; c < 8; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lfL[c][r] = load_sc1(Ls + 16 * c + (size_t)(16 * p) * mb + dcol[r]);
-      }
-      if constexpr (p > 0) {
-        if (nb > 0) flow_xload<T>(lf0, tile, mb, s + 1, s, p - 1, lo, dcol);
-        if (nb > 1) flow_xload<T>(lf1, tile, mb, s + 2, s, p - 1, lo, dcol);
-      }
-      acc_t nx;
-      if constexpr (p < 8) {
-        acc_t x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = T(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x = Tr<T>::mfma(wd[r], a[p][r], x);  // X_p^T = W_p A_p^T
-#pragma unroll
-        for (int r = 0; r < 4; ++r) store_sc1(Ab + (size_t)(16 * p) * mb + dcol[r], x[r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nx[r] = -x[r];
-#pragma unroll
-        for (int c = p + 1; c < 8; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[c] = Tr<T>::mfma(lfL[c][r], nx[r], a[c]);  // A_c -= X_p L(c,p)^T
-        if (critical || (is_head && p == 7)) {
-          flow_drain(fences);
-          if (!is_head && lane == 0) __hip_atomic_fetch_add(hp + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (p == 7 && lane == 0 && (ptile == 0 || count_all)) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      if constexpr (p > 0) {
-        if (nb > 0) flow_xmma<T>(acc0, lf0, nprev);
-        if (nb > 2) flow_xload<T>(lf0, tile, mb, s + 3, s, p - 1, lo, dcol);
-        if (nb > 1) flow_xmma<T>(acc1, lf1, nprev);
-        if (nb > 2) flow_xmma_lds<T>(mylds, lf0, nprev);
-      }
-      if constexpr (p < 8) {
-        if (!critical && !is_head) {
-          flow_drain(fences);
-          if (lane == 0) __hip_atomic_fetch_add(hp + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (p == 7 && lane == 0) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (p == 7) signalled = s + 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nprev[r] = nx[r];
-      }
-    });
-    if (!live) break;
-    if (blockIdx.x == 0 || (int)blockIdx.x == nin - 1 || (int)blockIdx.x == nin || blockIdx.x == gridDim.x - 1) dbg_mark(dbg, (is_head ? 20 : 10) + s, rb, t_step);
-    // the block one to the right becomes the next step's right-hand side
-    if (nb > 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = acc0[j];
-    }
-    if (nb > 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc0[j] = acc1[j];
-    }
-    if (nb > 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[j][r] = mylds[(j * 4 + r) * 64 + lane];
-    }
-  }
-  // aborted: the counters the launches on the other streams poll still have to come
-  if (lane == 0 && (ptile == 0 || count_all))
-    for (int s = signalled; s < rb; ++s) __hip_atomic_fetch_add(stepsem + 32 * s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  guest.leave();
-  if (blockIdx.x == 0 || (int)blockIdx.x == nin) dbg_mark(dbg, is_head ? 2 : 1, rb, t_in);
-}
-
 // ------------------------------------------------------------------------------
 // plgsy: the matrix CHAMELEON_dplgsy_Tile generates (v6_test.c:46).  Chameleon's published
 // generator (coreblas core_dplgsy, from PLASMA) is a 64-bit LCG ran <- a*ran + 1 addressed by
@@ -3088,86 +2482,52 @@ void launch_sem_probe(hipStream_t consumer, hipStream_t producer, int *sem, int 
 
 int *g_ytab = nullptr;                // per-CU yield requests (cooperative CU hand-over), may be null
 unsigned long long *g_dbg = nullptr;  // diagnostic stamp buffer (chol_debug_stamps)
-int g_variant = 5;  // fp64 trailing update: 0 four waves + LDS-DMA, 1 four waves + register staging, 2..5 eight waves (MODE = variant - 2: bit 0 DMA behind the first MFMAs, bit 1 static priority); fp32 always 0 / 1 (CHOLMI_VARIANT)
-int g_intile_small = 1;  // in-tile POTRF steps in small-block form (CHOLMI_INTILE=big: the 128 x 128 NT core)
 int g_min_units = 128;  // a launch is dealt in units small enough to give at least this many (CHOLMI_MIN_UNITS)
 int g_intile_fused = 1;  // chain-bound form: an in-tile step's solve and update in one launch (CHOLMI_INTILE_FUSED=0: two)
-int g_intile_fused_max = 256;  // ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3 (nr <= 10); beyond, resident pollers would queue for CU slots behind each other (CHOLMI_INTILE_FUSED_MAX)
+// ... while the step has at most this many polling update workgroups: nr (2 nr + 1), i.e. tiles up to 1024 + 128 x 3
+// (nr <= 10); beyond, resident pollers would queue for CU slots behind each other
+constexpr int INTILE_FUSED_MAX = 256;
 bool flow_applies(int nbm) { return g_flow && nbm >= g_flow_min_nbm && nbm <= g_flow_max_nbm; }
-int g_flow_rows = 1, g_flow_panel_max = 16;
-void launch_sem_set(hipStream_t s, int *sem) { k_sem_probe_set<<<1, 1, 0, s>>>(sem); }
-void launch_sem_gate(hipStream_t s, const int *sem, int target, int *fail) { k_sem_gate<<<1, 64, 0, s>>>(sem, target, fail); }
-int g_persist = 0;  // the far update launch (ST_MAIN) with a resident grid that deals itself its blocks (CHOLMI_PERSIST=1; experiment, round 4)
 int g_flow = 1;          // chain-bound waves: the tile POTRF as a flow of polling workgroups (CHOLMI_FLOW=0: diagonal-block + in-tile step launches)
-int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_MIN_NBM / _MAX_NBM): measured round 4, all waves
+int g_flow_min_nbm = 3, g_flow_max_nbm = 4;  // ... for tiles of this many 128-blocks (CHOLMI_FLOW_NBM=lo:hi): measured round 4, all waves
                                              // in flow form against none -- tile 512: +14 ... +17 % (N = 1536 ... 4096), +5 % (N = 5120, 6144); tile 256: -8 %
                                              // (a two-block tile has one in-tile step to save); tile 1024: -6 ... -12 % (the row waves' products pile up: 21 for the
                                              // last block row)
 int g_flow_fences = 0;   // ... 1: agent-scope release / acquire around every hand-off of the flow (CHOLMI_FLOW_FENCES; diagnostic)
 int g_poll_max_wgs = 48;  // grids up to this many workgroups poll their counter themselves, larger ones behind a gate (CHOLMI_POLL_MAX_WGS)
 int g_trsm_small_max = 64;  // panel TRSM steps in small-block form up to this many 128-row blocks (CHOLMI_TRSM_SMALL_MAX)
-int g_trsm_fused_min = 0;   // panel tiles from which the TRSM runs in its throughput form, k_trsm_fused (CHOLMI_TRSM_FUSED_MIN)
-int g_late_dma = 0;  // four-wave update (fp32; fp64 with CHOLMI_VARIANT=0): DMA behind the first MFMAs -- fp64 +0.9 %, fp32 -6.6 % (twice the MFMA rate: the burst is better out of the way early); CHOLMI_LATE_DMA
-int g_f32_w8 = 1;  // fp32 trailing update on eight waves with K-slices of 32 (CHOLMI_F32_W8=0: the four-wave kernel)
-int g_ablate = 0;  // diagnostic only (chol_bench_update): 1 no global loads, 2 no LDS reads, 4 no C read, 8 no barrier
+
+// blocks dealt to an XCD at a time (map_update_block) and the padded block counts of the two segments of a launch
+struct UpdateGrid {
+  int unit;
+  long blocks_a, blocks_b;
+};
+inline UpdateGrid update_grid(long tot_a, long tot_b, bool single_diag) {
+  UpdateGrid u;
+  u.unit = 64;
+  while (u.unit > 8 && (tot_a + tot_b) / u.unit < g_min_units) u.unit >>= 1;
+  u.blocks_a = ((tot_a + u.unit - 1) / u.unit + 7) / 8 * 8 * u.unit;
+  u.blocks_b = ((tot_b + u.unit - 1) / u.unit + 7) / 8 * 8 * u.unit;
+  if (single_diag) u.blocks_a = 0, u.blocks_b = tot_b;  // single diagonal tile: spread, no padding
+  return u;
+}
 
 template <typename T>
 void launch_trail_update(hipStream_t s, const LocalMat &C, const int2 *d_list, int off, int na, int offb,
-                         int nb, const PanelRef &pan, bool yield, const PanelRef *pan2, int *persist_ctr) {
+                         int nb, const PanelRef &pan, bool yield, const PanelRef *pan2) {
   if (na + nb <= 0) return;
   const int npan = pan2 ? 2 : 1;
   const PanelRef &p2 = pan2 ? *pan2 : pan;
   offb -= off;  // the kernels index from d_list + off
   const int nbm = C.mb / MACRO, MT = nbm * nbm, MTd = nbm * (nbm + 1) / 2;
-  const long tot_a = (long)na * MT, tot_b = (long)nb * MTd;
-  int unit = 64;  // blocks dealt to an XCD at a time (map_update_block)
-  while (unit > 8 && (tot_a + tot_b) / unit < g_min_units) unit >>= 1;
-  long blocks_a = ((tot_a + unit - 1) / unit + 7) / 8 * 8 * unit;
-  long blocks_b = ((tot_b + unit - 1) / unit + 7) / 8 * 8 * unit;
-  if (na == 0 && nb == 1) blocks_a = 0, blocks_b = MTd;  // single diagonal tile: spread, no padding
-  const dim3 grid((unsigned)(blocks_a + blocks_b)), blk(256);
-#ifdef CHOLMI_DIAGNOSTICS
-  if (g_ablate & 0x100) {  // diagnostic build of the same update (register staging, ablation switches)
-    k_trail_update_diag<T><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, g_ablate & 255);
-    return;
-  }
-#endif
-  if (g_variant >= 2 && sizeof(T) == 4 && g_f32_w8) {
-    if constexpr (sizeof(T) == 4)
-      k_trail_update_w8f<<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                   yield ? g_ytab : nullptr, p2, npan);
-    return;
-  }
-  if (g_variant >= 2 && sizeof(T) == 8 && persist_ctr && (blocks_a + blocks_b) > 1024) {
-    if constexpr (sizeof(T) == 8) {  // (the persistent form: launches of more than two rounds only)
-      (void)hipMemsetAsync(persist_ctr, 0, 8 * 32 * sizeof(int), s);
-      k_trail_update_w8p<T, 3><<<dim3(512), dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                               yield ? g_ytab : nullptr, p2, npan, persist_ctr,
-                                                               (int)(blocks_a + blocks_b));
-    }
-    return;
-  }
-  if (g_variant >= 2 && sizeof(T) == 8) {
-    if constexpr (sizeof(T) == 8) {
-#define W8(M) k_trail_update_w8<T, M><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit, \
-                                                     yield ? g_ytab : nullptr, p2, npan)
-      switch (g_variant - 2) {
-        case 1: W8(1); break;
-        case 2: W8(2); break;
-        case 3: W8(3); break;
-        default: W8(0); break;
-      }
-#undef W8
-    }
-  } else if (g_variant == 1)
-    k_trail_update<T, false><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                  yield ? g_ytab : nullptr, p2, npan);
-  else if (g_late_dma)
-    k_trail_update<T, true, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
-                                                       yield ? g_ytab : nullptr, p2, npan);
-  else
-    k_trail_update<T, true><<<grid, blk, 0, s>>>(C, d_list + off, na, offb, nb, (int)blocks_a, pan, nbm, unit,
+  const UpdateGrid u = update_grid((long)na * MT, (long)nb * MTd, na == 0 && nb == 1);
+  const dim3 grid((unsigned)(u.blocks_a + u.blocks_b));
+  if constexpr (sizeof(T) == 4)
+    k_trail_update_w8f<<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)u.blocks_a, pan, nbm, u.unit,
                                                  yield ? g_ytab : nullptr, p2, npan);
+  else
+    k_trail_update_w8<T, 3><<<grid, dim3(512), 0, s>>>(C, d_list + off, na, offb, nb, (int)u.blocks_a, pan, nbm, u.unit,
+                                                       yield ? g_ytab : nullptr, p2, npan);
 }
 
 // One 128-column step of the panel TRSM over `ntiles` tiles: X[:, st] = A[:, st] Winv_st^T, then
@@ -3181,7 +2541,6 @@ struct StepSems {
   const int *intile = nullptr;
   int intile_target = 0;
   int *head = nullptr;
-  bool head_all = false;  // `head` counts the solve's workgroups of EVERY tile (the column slices wait for the whole panel's step)
   int *fail = nullptr;
 };
 // (returns how many workgroups of the solve belong to the first tile: what `head` counts up to)
@@ -3189,10 +2548,10 @@ template <typename T>
 int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb, int st,
               T alpha, const StepSems &sm = StepSems()) {
   const int nbm = mb / MACRO, nc = nbm - 1 - st;
-  if (g_intile_small && alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
+  if (alpha == T(1) && ntiles * nbm <= g_trsm_small_max) {
     const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm * 4);
     k_solve_small<T><<<ntiles * nbm * 4, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, T(1), g_ytab,
-                                                      p1 ? sm.diag : nullptr, 1, sm.fail, sm.head, sm.head_all ? 1 : 0);
+                                                      p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
     if (nc > 0) {
       const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, 4L * nbm * nc * ntiles);
       k_small_update<T><<<dim3(2 * nbm, 2 * nc, ntiles), 256, 0, s>>>(
@@ -3200,19 +2559,19 @@ int trsm_step(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, cons
           lkk + (long)(st + 1) * MACRO + (long)st * MACRO * mb, mb, MACRO, g_ytab, 1, bsiz, bsiz, nullptr,
           p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
     }
-    return 4 * nbm * (sm.head_all ? ntiles : 1);
+    return 4 * nbm;
   }
   // alpha is applied once to every column block: in the solve of block 0 and as the beta of the
   // first update of blocks > 0
   const bool p1 = poll_in_kernel(s, sm.diag, 1, sm.fail, (long)ntiles * nbm);
   k_panel_solve<T><<<ntiles * nbm, 256, 0, s>>>(tiles, bsiz, mb, nbm, 0, st, winv, st == 0 ? alpha : T(1), g_ytab,
-                                                p1 ? sm.diag : nullptr, 1, sm.fail, sm.head, sm.head_all ? 1 : 0);
+                                                p1 ? sm.diag : nullptr, 1, sm.fail, sm.head);
   if (nc > 0) {
     const bool p2 = poll_in_kernel(s, sm.intile, sm.intile_target, sm.fail, (long)ntiles * nbm * nc);
     k_panel_update<T><<<ntiles * nbm * nc, 256, 0, s>>>(tiles, bsiz, mb, nbm, st, lkk, st == 0 ? alpha : T(1), g_ytab,
                                                         p2 ? sm.intile : nullptr, sm.intile_target, sm.fail);
   }
-  return nbm * (sm.head_all ? ntiles : 1);
+  return nbm;
 }
 
 // Column k+1 below its diagonal tile in the LATENCY form: C_i -= A_i B^T, i = 0 .. ntiles-1 (tiles bsiz apart, B the head
@@ -3236,7 +2595,7 @@ void launch_diag_syrk(hipStream_t s, T *C, const T *A, int mb) {
 template <typename T>
 void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int info_base, int *sem) {
   const int nbm = mb / MACRO;
-  const bool fused_steps = sem && g_intile_small && g_intile_fused && nbm > 1;
+  const bool fused_steps = sem && g_intile_fused && nbm > 1;
   if (fused_steps) (void)hipMemsetAsync(sem, 0, (size_t)nbm * 32 * sizeof(int), s);
   for (int st = 0; st < nbm; ++st) {
     k_potrf_diag<T><<<1, 256, 0, s>>>(tile + (long)st * MACRO * (mb + 1), mb,
@@ -3244,33 +2603,15 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
     const int nr = nbm - 1 - st;
     if (nr > 0) {
       // the in-tile POTRF steps are a handful of workgroups on the critical path: guests
-      if (fused_steps && nr * (2 * nr + 1) <= g_intile_fused_max) {
+      if (fused_steps && nr * (2 * nr + 1) <= INTILE_FUSED_MAX) {
         k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, s>>>(tile, mb, nbm, st, winv, g_ytab, sem + 32 * st, d_info);
-      } else if (g_intile_small) {
-        k_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, 0, mb, nbm, st + 1, st, winv, T(1), g_ytab);
-        {
-          T *tr = tile + (long)(st + 1) * MACRO * (mb + 1);  // trailing part of the tile
-          const T *xs = tile + (long)(st + 1) * MACRO + (long)st * MACRO * mb;  // block column st below the diagonal
-          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, s>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
-        }
       } else {
-        k_panel_solve<T><<<nr, 256, 0, s>>>(tile, (long)mb * mb, mb, nbm, st + 1, st, winv, T(1), g_ytab);
-        k_intile_update<T><<<dim3(nr, nr), 256, 0, s>>>(tile, mb, nbm, st, g_ytab);
+        k_solve_small<T><<<4 * nr, 256, 0, s>>>(tile, 0, mb, nbm, st + 1, st, winv, T(1), g_ytab);
+        T *tr = tile + (long)(st + 1) * MACRO * (mb + 1);  // trailing part of the tile
+        const T *xs = tile + (long)(st + 1) * MACRO + (long)st * MACRO * mb;  // block column st below the diagonal
+        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, s>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
       }
     }
-  }
-}
-
-// throughput form of the panel TRSM (fp64, alpha = 1): one launch for all tiles; needs the whole factored
-// diagonal tile and all its block inverses
-template <typename T>
-bool trsm_fused_applies(int ntiles, int mb) {
-  return sizeof(T) == 8 && mb >= 2 * MACRO && g_trsm_fused_min > 0 && ntiles >= g_trsm_fused_min;
-}
-template <typename T>
-void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *lkk, const T *winv, int mb) {
-  if constexpr (sizeof(T) == 8) {
-    if (ntiles > 0) k_trsm_fused<T><<<ntiles * (mb / MACRO), 256, 0, s>>>(tiles, bsiz, mb, mb / MACRO, lkk, winv);
   }
 }
 
@@ -3278,10 +2619,7 @@ void launch_trsm_fused(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
 // TRSM step s needs only Winv_s and the blocks L(c,s), c > s, of the diagonal tile, which exist
 // as soon as in-tile step s is done -- so it runs on `st` while the POTRF goes on with step s+1
 // on `sp`.  The chain of a wave shrinks from POTRF + TRSM to about POTRF + one TRSM step.
-// A long panel is solved in the throughput form instead (one launch once the POTRF is complete);
-// only its head tile -- the one the next diagonal tile's SYRK, and with it the next POTRF, waits
-// for -- still follows the POTRF step by step.  ev_head (may be null) is recorded on `st` when the
-// head tile is done.
+// ev_head (may be null) is recorded on `st` when the panel is solved.
 // ev: nbm events.  Both streams must be joined by the caller.
 // sy != null: the counter-linked form of a chain-bound wave (SyrkPipe) -- the same launches, plus the SYRK
 // on the next diagonal tile in K = 128 slices on sy->su, every dependency between the streams a polled
@@ -3292,36 +2630,24 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
                             const SyrkPipe *sy, const int *wait_sem, int wait_target) {
   const int nbm = mb / MACRO;
-  const bool fused = trsm_fused_applies<T>(ntiles - 1, mb);
-  // (SyrkPipe needs the step-by-step TRSM of the whole panel; the walker does not combine it with the fused form)
-  const bool pipe = sy && !fused && ntiles > 0;
-  const int nstep = fused ? 1 : ntiles;  // tiles that follow the POTRF step by step
+  const bool pipe = sy && ntiles > 0;
   // pipe: counters of this wave, one 128-byte slot each -- D[s] the diagonal-block step s, I[s] the in-tile
   // solve of step s (4 nr workgroups), H[s] the head tile's workgroups of TRSM step s, then `done`
   auto slot = [&](int i) { return sy->sem + 32 * i; };
   // the tile POTRF as a flow (k_flow_factor / k_flow_rows): the diagonal-block steps raise D[s] as before, the
   // row-slab waves I[s] (8 (nbm - 1 - s) of them instead of the 4 (nbm - 1 - s) workgroups of the in-tile solve)
   const bool flow = pipe && sy->fc && sy->sflow && flow_applies(nbm);
-  const bool rows2 = flow && g_flow_rows >= 2 && nbm <= 4;  // (the streaming row slabs keep two blocks ahead in registers)
-  // ... which then take the head tile's rows along: TRSM step s covers the panel's other tiles only, H[s] counts waves
-  const bool head_flow = rows2 && g_flow_rows >= 3 && sy->head_flow && sy->c && nstep >= 1;
-  // ... and the panel's other tiles, while there are few of them (g_flow_rows >= 4): no TRSM launch is left
-  const int nflow = !head_flow ? 0 : g_flow_rows >= 4 && nstep <= g_flow_panel_max ? nstep : 1;
   if (flow) {
-    if (sy->join_flow && sy->ev_flow) {  // first flow-form wave: the flow stream joins the POTRF stream's order once (without it the
-                                         // row-slab kernel would sit on the chip, polling, from the moment the host issues it)
+    if (sy->join_flow && sy->ev_flow) {  // the flow stream joins the POTRF stream's order (without it the row-slab kernel
+                                         // would sit on the chip, polling, from the moment the host issues it -- and read
+                                         // its rows of the tile before the updates of the waves before have written them)
       (void)hipEventRecord(sy->ev_flow, sp);
       (void)hipStreamWaitEvent(sy->sflow, sy->ev_flow, 0);
     }
     k_flow_factor<T><<<nbm, 256, 0, sp>>>(lkk, mb, nbm, winv, d_info, info_base, sy->fc, g_ytab, wait_sem, wait_target,
                                           slot(0), g_flow_fences, g_dbg);
-    if (rows2)
-      k_flow_rows2<T><<<(mb - MACRO) / 64 + nflow * (mb / 64), 256, 0, sy->sflow>>>(
-          lkk, tiles, bsiz, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem, wait_target, head_flow ? sy->head_ready : nullptr, slot(nbm),
-          slot(2 * nbm), sy->col_slices ? 1 : 0, g_flow_fences, g_dbg);
-    else
-      k_flow_rows<T><<<(mb - MACRO) / 64, 256, 0, sy->sflow>>>(lkk, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem, wait_target,
-                                                             slot(nbm), g_flow_fences, g_dbg);
+    k_flow_rows<T><<<(mb - MACRO) / 64, 256, 0, sy->sflow>>>(lkk, mb, nbm, winv, d_info, sy->fc, g_ytab, wait_sem, wait_target,
+                                                           slot(nbm), g_flow_fences, g_dbg);
   }
   for (int s = 0; s < nbm; ++s) {
     const int nr = nbm - 1 - s;
@@ -3330,25 +2656,20 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                          d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
                                          wait_target, pipe ? slot(s) : nullptr);
     if (nr > 0 && !flow) {
-      if (g_intile_small) {
-        if (pipe && g_intile_fused && nr * (2 * nr + 1) <= g_intile_fused_max) {
-          // solve and update of the step in one launch, the update's workgroups polling the solves' counter
-          // (which the TRSM step's update on st polls too)
-          k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab, slot(nbm + s),
-                                                                       d_info);
-        } else {
-          k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
-                                                   pipe ? slot(nbm + s) : nullptr);
-          T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
-          const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
-          // (launching the update ahead of time on another stream, polling the in-tile solve's counter, the
-          // next diagonal-block step polling its own: -1 ... -5 % on st, -10 ... -20 % on su -- it queues
-          // behind that stream's own launches)
-          k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
-        }
+      if (pipe && g_intile_fused && nr * (2 * nr + 1) <= INTILE_FUSED_MAX) {
+        // solve and update of the step in one launch, the update's workgroups polling the solves' counter
+        // (which the TRSM step's update on st polls too)
+        k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab, slot(nbm + s),
+                                                                     d_info);
       } else {
-        k_panel_solve<T><<<nr, 256, 0, sp>>>(lkk, (long)mb * mb, mb, nbm, s + 1, s, winv, T(1), g_ytab);
-        k_intile_update<T><<<dim3(nr, nr), 256, 0, sp>>>(lkk, mb, nbm, s, g_ytab);
+        k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
+                                                 pipe ? slot(nbm + s) : nullptr);
+        T *tr = lkk + (long)(s + 1) * MACRO * (mb + 1);
+        const T *xs = lkk + (long)(s + 1) * MACRO + (long)s * MACRO * mb;
+        // (launching the update ahead of time on another stream, polling the in-tile solve's counter, the
+        // next diagonal-block step polling its own: -1 ... -5 % on st, -10 ... -20 % on su -- it queues
+        // behind that stream's own launches)
+        k_small_update<T><<<dim3(2 * nr, 2 * nr), 256, 0, sp>>>(tr, mb, xs, xs, mb, MACRO, g_ytab, 0, 0, 0);
       }
     }
     if (ntiles <= 0) continue;
@@ -3360,42 +2681,25 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
       ss.intile = slot(nbm + s);
       ss.intile_target = (flow ? 8 : 4) * nr;
       ss.head = sy->c ? slot(2 * nbm + s) : nullptr;
-      ss.head_all = sy->col_slices || (sy->panel_done_all && s == nbm - 1 && !head_flow && sy->c);
       ss.fail = d_info;
-      int head_wgs = mb / 16;
-      if (head_flow) {
-        // H[s]: the head tile's waves -- or, with column slices, every wave and workgroup that solves a tile of the panel
-        if (!sy->col_slices) ss.head = nullptr;
-        int more = 0;
-        if (nstep > nflow) more = trsm_step<T>(st, tiles + nflow * bsiz, bsiz, nstep - nflow, lkk, winv, mb, s, T(1), ss);
-        if (sy->col_slices) head_wgs = nflow * (mb / 16) + more;
-      } else {
-        head_wgs = trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1), ss);
-        if (s == nbm - 1) sy->panel_target = ss.head_all ? head_wgs : 0;
-      }
+      const int head_wgs = trsm_step<T>(st, tiles, bsiz, ntiles, lkk, winv, mb, s, T(1), ss);
       if (!sy->c) continue;  // (a grid: the POTRF -> TRSM edge alone runs on counters, the next diagonal tile is elsewhere)
       const T *xs = tiles + (long)s * MACRO * mb;
       const int n64 = mb / 64;
-      const long nslice = (long)n64 * (n64 + 1) / 2, noff = sy->col_slices ? (long)(nstep - 1) * n64 * n64 : 0;
+      const long nslice = (long)n64 * (n64 + 1) / 2;
       int *done = s == nbm - 1 ? slot(3 * nbm) : nullptr;
-      const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice + noff);
+      const bool ps = poll_in_kernel(sy->su, slot(2 * nbm + s), head_wgs, d_info, nslice);
       k_small_update<T><<<dim3(n64, n64), 256, 0, sy->su>>>(reinterpret_cast<T *>(sy->c), mb, xs, xs, mb, MACRO, g_ytab, 0, 0,
                                                            0, done, ps ? slot(2 * nbm + s) : nullptr, head_wgs, d_info);
-      // column slices: the same K = 128 slice for every tile of column k+1 below its diagonal tile, so that when the
-      // panel's last step is done ONE slice is left of what the next wave's TRSM waits for, not a K = mb launch
-      if (noff > 0)
-        k_small_update<T><<<dim3(n64, n64, nstep - 1), 256, 0, sy->su>>>(reinterpret_cast<T *>(sy->c) + bsiz, mb, xs + bsiz, xs, mb,
-                                                                         MACRO, g_ytab, 1, bsiz, bsiz, done);
       continue;
     }
     // (recorded behind the in-tile update, not between the solve and the update: an event record
     // between two dependent launches of the chain costs it ~7 us, the TRSM step loses nothing)
     (void)hipEventRecord(ev[s], sp);
     (void)hipStreamWaitEvent(st, ev[s], 0);
-    trsm_step<T>(st, tiles, bsiz, nstep, lkk, winv, mb, s, T(1));
+    trsm_step<T>(st, tiles, bsiz, ntiles, lkk, winv, mb, s, T(1));
   }
   if (ev_head) (void)hipEventRecord(ev_head, st);
-  if (fused) launch_trsm_fused<T>(st, tiles + bsiz, bsiz, ntiles - 1, lkk, winv, mb);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
                                              int *, int, double *, long, int, hipEvent_t, const SyrkPipe *, const int *, int);
@@ -3415,10 +2719,6 @@ void launch_trsm_panel(hipStream_t s, T *tiles, long bsiz, int ntiles, const T *
                        int mb, T alpha) {
   if (ntiles <= 0) return;
   const int nbm = mb / MACRO;
-  if (alpha == T(1) && trsm_fused_applies<T>(ntiles, mb)) {
-    launch_trsm_fused<T>(s, tiles, bsiz, ntiles, lkk, winv, mb);
-    return;
-  }
   // the TRSM of the next panel outranks the trailing update whenever the update yields at all (the
   // walker enables that only while the panel chain is the critical path)
   for (int st = 0; st < nbm; ++st) trsm_step<T>(s, tiles, bsiz, ntiles, lkk, winv, mb, st, alpha);
@@ -3530,7 +2830,7 @@ template void launch_mfma_probe<float>(hipStream_t, float *, int, int);
 
 #define INSTANTIATE(T)                                                                              \
   template void launch_trail_update<T>(hipStream_t, const LocalMat &, const int2 *, int, int, int,  \
-                                       int, const PanelRef &, bool, const PanelRef *, int *);       \
+                                       int, const PanelRef &, bool, const PanelRef *);              \
   template void launch_potrf_tile<T>(hipStream_t, T *, int, T *, int *, int, int *);                \
   template void launch_diag_syrk<T>(hipStream_t, T *, const T *, int);                               \
   template void launch_invert_diag<T>(hipStream_t, const T *, int, T *);                            \

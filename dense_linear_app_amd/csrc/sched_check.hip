@@ -7,9 +7,13 @@
 // names.  On a p x q grid the check is per rank: sends read and receives write (tiles and the rotating receive buffers) on
 // the stream they are issued on; what the OTHER ranks do is tests/test_dist_cabi_gloo.py's business.
 //
-// Granularity: o.panel() is one POTRF launch (ST_PANEL; with the flow form also ST_CX), one TRSM launch over the whole
-// panel (ST_TRSM, behind it), and in counter-linked waves one launch for the SYRK slices (ST_U1, behind the TRSM) --
-// what happens between those three is kernels.hip's business (launch_panel_pipelined) and is tested on the GPU.
+// Granularity: o.panel() is one POTRF launch (ST_PANEL), one TRSM launch over the whole panel (ST_TRSM, behind it), and
+// in counter-linked waves one launch for the SYRK slices (ST_U1, behind the TRSM) -- what happens between those three is
+// kernels.hip's business (launch_panel_pipelined) and is tested on the GPU.  The flow form of the tile POTRF is TWO
+// launches: the factorisation (k_flow_factor, ST_PANEL) and the row slabs (k_flow_rows, ST_CX), each with the
+// dependencies its own stream gives it -- the row slabs have ST_PANEL's only through the join event (sy->join_flow) or
+// the counter both kernels poll (wait_sem); the two hand panels to each other inside the kernels (not checked here:
+// tests/test_gpu_full.py, CHOLMI_FLOW_FENCES A/B) and are therefore exempt from the pairwise check AGAINST EACH OTHER.
 #include <bitset>
 #include <cstdint>
 #include <cstdio>
@@ -41,6 +45,7 @@ struct TraceOps {
   std::map<const int *, int> producer;   // a counter: the launch that raises it to its target
   std::vector<int> sems;
   std::vector<std::string> findings;
+  std::set<std::pair<int, int>> coop;     // pairs of launches that cooperate through in-kernel counters (flow form)
   int drop_wait = -1, drop_gate = -1, nwaits = 0, ngates = 0;  // self-test: the n-th event wait / gate is ignored
   std::string dropped;
   // the address space: this rank's lmt x lnt tiles, the two block-inverse workspaces, then whatever the walker allocates
@@ -137,20 +142,6 @@ struct TraceOps {
     pending[st].insert(it->second.begin(), it->second.end());
     return 0;
   }
-  int gate(int st, const int *sem, int) {
-    if (ngates++ == drop_gate) return 0;
-    auto it = producer.find(sem);
-    if (it == producer.end()) {
-      findings.push_back("a stream is gated on a counter nobody has been asked to raise");
-      return 0;
-    }
-    pending[st].insert(it->second);
-    return 0;
-  }
-  int signal(int st, int *sem) {
-    producer[sem] = add(1u << st, "signal", {});
-    return 0;
-  }
   int panel(int k, char *lkk, void *wv, char *tiles, int ntiles, int, int ev_head, const SyrkPipe *sy, const int *wait_sem, int) {
     std::vector<int> extra;
     if (wait_sem && ngates++ != drop_gate) {
@@ -158,28 +149,42 @@ struct TraceOps {
       if (it == producer.end()) findings.push_back("POTRF(" + std::to_string(k) + ") polls a counter nobody raises");
       else extra.push_back(it->second);
     }
-    const bool flow = sy && sy->fc && sy->sflow;
+    const bool flow = sy && sy->fc && sy->sflow && flow_applies(g.nbm);
+    // the flow's join: an event recorded on ST_PANEL ahead of the factorisation launch, waited for by ST_CX (kernels.hip:
+    // launch_panel_pipelined) -- counted and droppable like every other event wait
+    std::vector<int> rows_extra = extra;
+    if (flow && sy->join_flow) {
+      if (nwaits++ == drop_wait) {
+        dropped = "(dropped: the flow stream's join of wave " + std::to_string(k) + ")";
+      } else {
+        if (last_on[ST_PANEL] >= 0) rows_extra.push_back(last_on[ST_PANEL]);
+        rows_extra.insert(rows_extra.end(), pending[ST_PANEL].begin(), pending[ST_PANEL].end());
+      }
+    }
     Acc pa;
     touch(pa, lkk, g.tile_bytes, true);
     touch(pa, wv, std::max<size_t>(1, g.winv_bytes), true);
-    const int potrf = add((1u << ST_PANEL) | (flow ? 1u << ST_CX : 0u), "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow]" : ""), pa, extra);
+    const int potrf = add(1u << ST_PANEL, "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow: factor]" : ""), pa, extra);
+    std::vector<int> after = {potrf};
+    if (flow) {
+      Acc ra;
+      touch(ra, lkk, g.tile_bytes, true);
+      touch(ra, wv, std::max<size_t>(1, g.winv_bytes), false);
+      const int rows = add(1u << ST_CX, "POTRF(" + std::to_string(k) + ") [flow: row slabs]", ra, rows_extra);
+      coop.insert({potrf, rows});
+      after.push_back(rows);  // (the TRSM steps poll D[s], raised by the factorisation, and I[s], raised by the row slabs)
+    }
     if (ntiles <= 0) return 0;
     Acc acc;
     touch(acc, lkk, g.tile_bytes, false);
     touch(acc, wv, std::max<size_t>(1, g.winv_bytes), false);
     touch(acc, tiles, (size_t)ntiles * g.tile_bytes, true);
-    const bool head_flow = flow && sy->head_flow;
-    const int trsm = add((1u << ST_TRSM) | (head_flow ? 1u << ST_CX : 0u), "TRSM(" + std::to_string(k) + ")", acc, {potrf});
+    const int trsm = add(1u << ST_TRSM, "TRSM(" + std::to_string(k) + ")", acc, after);
     if (ev_head >= 0) ev_deps[ev_head] = {trsm};
-    if (sy && sy->sem) producer[sy->sem + 32 * (3 * g.nbm - 1)] = trsm;  // H[nbm-1] ("panel complete" when it counts every tile)
     if (sy && sy->c && sy->su) {  // (one GPU: the tiles of a column are contiguous)
       Acc sa;
       touch(sa, tiles, g.tile_bytes, false);
       touch(sa, sy->c, g.tile_bytes, true);
-      if (sy->col_slices && ntiles > 1) {
-        touch(sa, tiles + g.tile_bytes, (size_t)(ntiles - 1) * g.tile_bytes, false);
-        touch(sa, (char *)sy->c + g.tile_bytes, (size_t)(ntiles - 1) * g.tile_bytes, true);
-      }
       const int sl = add(1u << ST_U1, "SYRK slices(" + std::to_string(k) + ")", sa, {trsm});
       producer[sy->sem + 32 * (3 * g.nbm)] = sl;
     }
@@ -227,14 +232,13 @@ struct TraceOps {
     add(1u << st, b, acc);
     return 0;
   }
-  int update_col_small(int k, int st, int *done) {
+  int update_col_small(int k, int st) {
     const int n = g.nt - k - 2;
     Acc acc;
     touch(acc, tile(k + 1, k), g.tile_bytes, false);
     touch(acc, tile(k + 2, k), (size_t)n * g.tile_bytes, false);
     touch(acc, tile(k + 2, k + 1), (size_t)n * g.tile_bytes, true);
-    const int id = add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
-    if (done) producer[done] = id;
+    add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
     return 0;
   }
   // the transport of a grid: a send reads, a receive writes, on the stream it is issued on
@@ -278,6 +282,7 @@ struct TraceOps {
       for (size_t b = 1; b < v.size(); ++b)
         for (size_t a = 0; a < b; ++a) {
           if (v[a].first == v[b].first || (!v[a].second && !v[b].second)) continue;
+          if (coop.count({v[a].first, v[b].first})) continue;
           if (!(*reach)[v[b].first].test(v[a].first)) {
             char buf[480];
             snprintf(buf, sizeof buf, "%s: '%s' (%s) and '%s' (%s) are not ordered", slot_name(kv.first).c_str(), ops[v[a].first].name.c_str(),
@@ -304,8 +309,6 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   TraceOps ops(g, profiling != 0);
   WaveCalib c;
   c.t_tile = t_tile, c.t_panel = t_panel;
-  const int rows_saved = g_flow_rows;
-  if (const char *e = getenv("CHOLMI_FLOW_ROWS")) g_flow_rows = atoi(e);
   // (self-test of the checker: CHOLMI_CHECK_DROP_WAIT / _DROP_GATE = n makes it ignore the n-th event wait / counter edge the
   // walker asks for -- a schedule with that dependency missing, which it has to report unless the edge was redundant)
   if (const char *e = getenv("CHOLMI_CHECK_DROP_WAIT")) ops.drop_wait = atoi(e);
@@ -323,7 +326,6 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   long long info = 0;
   int rc = w.setup();
   if (!rc) rc = w.run(&info);
-  g_flow_rows = rows_saved;
   if (rc) return rc < 0 ? rc : -rc;
   std::string out;
   for (auto &f : ops.findings) out += f + "\n";

@@ -88,34 +88,28 @@ struct WaveCalib {
   double t_panel = 0;  // the panel chain of one wave (mb/128 dependent steps)
 };
 
-// switches of the schedule (environment, read once; CHOLMI_* names in DESIGN.md section 4)
+// switches of the schedule (environment, read once; what each is for: INTEGRATION.md section 5).  Every factor is
+// a threshold on (a wave's update time) / (its panel chain's time), both estimated from chol_init's calibration:
+//   pair_fac   >= : panels in pairs (0: always, large: never)        yfac     < : the update's waves yield their CU to the chain
+//   pipe_fac   <  : the counter-linked chain (0: never)              near_fac < : ... with column k+2 as a launch of its own (0: never)
+//   flow_fac   <  : ... with the tile POTRF as a flow, per wave (default -1: by flow_run_fac on the whole factorisation)
 struct WaveSwitches {
-  int pair_max_mb = 1024;
   double pair_fac = 2.0, yfac = 3.0, pipe_fac = 0.7, flow_fac = -1.0, halves_max_rounds = 24.0, near_fac = 0.7, flow_run_fac = 1.0;
-  bool syrk_pipe = true, split_always = false, head_first = true, col_slices = false, pipe_near = true, u1_counters = false;
   int u1_small_max = 8;  // counter-linked waves: column k+1 in the latency form while it has at most this many tiles below the diagonal (CHOLMI_U1_SMALL)
-  // first wave of the first pair: 1 -- wave 0 stays plain, so that its whole update runs beside panel 1's chain
-  // (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside that chain)
-  int pair_start = 1;
   WaveSwitches() {
-    if (const char *e = getenv("CHOLMI_PAIR_START")) pair_start = atoi(e) != 0;
-    if (const char *e = getenv("CHOLMI_PAIR_MAX_MB")) pair_max_mb = atoi(e);
     if (const char *e = getenv("CHOLMI_PAIR_FACTOR")) pair_fac = atof(e);
     if (const char *e = getenv("CHOLMI_YIELD_FACTOR")) yfac = atof(e);
     if (const char *e = getenv("CHOLMI_PIPE_FACTOR")) pipe_fac = atof(e);
     if (const char *e = getenv("CHOLMI_FLOW_FACTOR")) flow_fac = atof(e);
     if (const char *e = getenv("CHOLMI_FLOW_RUN_FACTOR")) flow_run_fac = atof(e);
     if (const char *e = getenv("CHOLMI_HALVES_MAX_ROUNDS")) halves_max_rounds = atof(e);
-    if (const char *e = getenv("CHOLMI_SYRK_PIPE")) syrk_pipe = atoi(e) != 0;
-    if (const char *e = getenv("CHOLMI_HEAD_FIRST")) head_first = atoi(e) != 0;
-    if (const char *e = getenv("CHOLMI_COL_SLICES")) col_slices = atoi(e) != 0;
-    if (const char *e = getenv("CHOLMI_PIPE_NEAR")) pipe_near = atoi(e) != 0;
     if (const char *e = getenv("CHOLMI_NEAR_FACTOR")) near_fac = atof(e);
     if (const char *e = getenv("CHOLMI_U1_SMALL")) u1_small_max = atoi(e);
-    if (const char *e = getenv("CHOLMI_U1_COUNTERS")) u1_counters = atoi(e) != 0;
-    split_always = getenv("CHOLMI_SPLIT_U1") != nullptr;
   }
 };
+// panels go in pairs only for tiles up to this edge, and from wave 1 on: wave 0 stays plain, so that its whole update runs
+// beside panel 1's chain (with pairs from wave 0 on, the far columns' update by panel 0 is deferred and nothing runs beside it)
+constexpr int PAIR_MAX_MB = 1024, PAIR_START = 1;
 
 // two transport channels (include/cholmi.h: chol_transport_t), one per communication stream, so that the
 // diagonal tile of wave k+1 never queues behind the exchange of panel k inside one communicator
@@ -183,6 +177,9 @@ struct Walker {
   int last_lkk[2] = {-1, -1}, last_head[2] = {-1, -1};
   double issue_us = 0, upd_flops = 0;
   int upd_launches = 0, flow_waves = 0;
+  // how many waves ran in which regime (chol_last_potrf_regimes): a number can be tied to its schedule afterwards
+  enum { R_PAIRED, R_PLAIN, R_HALVES, R_PIPE, R_NEAR1, R_FLOW, R_YIELD, R_U1SMALL, R_COUNT };
+  int regimes[R_COUNT] = {};
   std::vector<int> halves_waves;
 
   Walker(O &ops, const WaveGeo &geo, WaveComm *comm, const WaveCalib &c) : o(ops), g(geo), cm(comm), cal(c) {}
@@ -335,8 +332,7 @@ struct Walker {
     const auto t_host0 = std::chrono::steady_clock::now();
     const int nt = g.nt, mb = g.mb, nbm = g.nbm, P = g.P, Q = g.Q;
     const bool mr = multi();
-    const int sem_per_wave = 3 * nbm + 3 + flow_ctl_lines(nbm);  // SyrkPipe's counters, the flow's control block, `head tile ready`, `column k+1 updated`
-    const int sem_head_ready = 3 * nbm + 1 + flow_ctl_lines(nbm), sem_u1_done = sem_head_ready + 1;
+    const int sem_per_wave = 3 * nbm + 1 + flow_ctl_lines(nbm);  // SyrkPipe's counters, the flow's control block
     WRC(o.begin(E_PER_WAVE * nt + F_FIXED + nbm + 1, nt, sem_per_wave));
     const int ev_steps = fx(F_FIXED);
     WRC(o.rec(fx(F_START), ST_MAIN));
@@ -344,9 +340,7 @@ struct Walker {
     bool paired = false, cols_pending = false, had_pairs = false;
     int open_bracket = -1;  // odd wave whose profiling bracket is still open
     int bnd = -1;
-    bool prev_halves = false, prev_flow = false, prev_colsl = false, flow_joined = false;
-    int u1_target_prev = 0;  // > 0: the last wave's column-(k+1) launch raises a counter, up to this
-    bool head_sig_next = false;  // the last wave raised this wave's `head tile ready` counter behind its column update
+    bool prev_halves = false, prev_flow = false, flow_joined = false;
     const bool flags = !mr && o.counters();
     // On a grid only ONE of the chain's edges is local to a rank: POTRF steps -> its own panel tiles' TRSM steps, on the
     // owner of (k,k).  (The other -- last SYRK slice -> next POTRF -- never is: tile (k+1,k+1) belongs to another rank.)
@@ -363,12 +357,6 @@ struct Walker {
     const bool prof = o.profiling();
     for (int k = 0; k < nt; ++k) {
       const int dr = k % P, dc = k % Q, par = k & 1;
-      const bool head_sig = head_sig_next;
-      head_sig_next = false;
-      bool head_flow = false;  // the flow's row-slab launch solves the head tile L(k+1,k) too
-      const int u1_target_last = u1_target_prev;
-      u1_target_prev = 0;
-      int panel_target = 0;  // > 0: H[nbm-1] of this wave counts up to this when the panel is complete
       const bool in_col = g.pc == dc, own_diag = in_col && g.pr == dr, last = k + 1 >= nt;
       int il0m = 0, cntm = 0;
       g.part(k, g.pr, &il0m, &cntm);
@@ -378,31 +366,24 @@ struct Walker {
       // (ST_TRSM needs no event for the start of the wave: its first step waits for the event recorded on
       // ST_PANEL behind the first diagonal-block step, and a record on ST_PANEL costs the chain ~7 us)
       const int local_tiles = g.tiles_in(k + 1, nt);  // this rank's tiles of wave k's update
-      const bool pair_first = k >= sw.pair_start && ((k - sw.pair_start) & 1) == 0;
+      const bool pair_first = k >= PAIR_START && ((k - PAIR_START) & 1) == 0;
       if (pair_first)
-        paired = mb <= sw.pair_max_mb && k + 2 < nt && (double)local_tiles * t_tile >= sw.pair_fac * t_panel;
+        paired = mb <= PAIR_MAX_MB && k + 2 < nt && (double)local_tiles * t_tile >= sw.pair_fac * t_panel;
       // Plain (unpaired) wave whose panel chain is (nearly) critical: the SYRK on tile (k+1,k+1) follows the
       // head tile's TRSM steps slice by slice and the chain's cross-stream edges are device-side counters
       // (only while the update is shorter than about a panel chain: the polling workgroups hold CU slots the
       // update would otherwise use -- measured +10 ... +20 % on the waves between pipe_fac and the yield threshold)
       const bool plain_yield = (double)local_tiles * t_tile < sw.yfac * t_panel;
       const bool chain_bound = (double)local_tiles * t_tile < sw.pipe_fac * t_panel;
-      const bool pipe = sw.syrk_pipe && flags && !paired && !last && o.pipe_ok() && plain_yield && chain_bound;
-      const bool pipe_local = sw.syrk_pipe && flags_local && !paired && o.pipe_ok() && plain_yield && chain_bound && own_diag && cntm > 0;
+      const bool pipe = flags && !paired && !last && o.pipe_ok() && plain_yield && chain_bound;
+      const bool pipe_local = flags_local && !paired && o.pipe_ok() && plain_yield && chain_bound && own_diag && cntm > 0;
       // ... with its tile POTRF as a flow (kernels.hip: k_flow_factor) when the WHOLE factorisation is chain-bound (wave 0
       // already is): measured round 4, the form gains 14-17 % there (tile 512, N <= 4096) and nothing when only the last
       // waves of a larger matrix use it -- the wave that switches forms pays ~90 us, the rest gains ~40 us each
       // (CHOLMI_FLOW_FACTOR = f > 0: instead, every wave whose update is shorter than f panel estimates)
       const bool flow = pipe && own_diag && cntm > 0 && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm) &&
                         (sw.flow_fac > 0 ? (double)local_tiles * t_tile < sw.flow_fac * t_panel : flow_run);
-      // ... and with column k+1 updated in K = 128 slices behind the panel's steps instead of by a launch that waits for
-      // the whole panel: the cycle TRSM(k) -> column-(k+1) update -> TRSM(k+1) shrinks to one slice.  The next wave's
-      // TRSM needs no event for it: its first step polls D[0], whose kernel has polled the last slice's counter.
-      const bool colsl = pipe && sw.col_slices && own_diag && cntm > 0;
-      if (k > 0 && in_col && !(prev_colsl && pipe)) {
-        if (u1_target_last > 0) WRC(o.gate(ST_TRSM, o.sem(k - 1, sem_u1_done, sem_per_wave), u1_target_last));
-        else WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
-      }
+      if (k > 0 && in_col) WRC(o.wt(ST_TRSM, ev(k - 1, E_U1R)));
       // block inverses of L(k,k): two workspaces alternating by wave, so that POTRF(k+1) may overwrite its
       // set while TRSM(k) still reads the other
       const char *head = nullptr;
@@ -422,26 +403,22 @@ struct Walker {
           sy.c = o.tile((k + 1) / P, (k + 1) / Q);
           sy.su = (hipStream_t)o.stream(ST_U1);
           sy.sem = o.sem(k, 0, sem_per_wave);
-          sy.col_slices = colsl;
-          sy.panel_done_all = sw.u1_counters && !colsl;
           if (flow) {
             sy.fc = o.sem(k, 3 * nbm + 1, sem_per_wave);
             sy.sflow = (hipStream_t)o.stream(ST_CX);
             sy.ev_flow = (hipEvent_t)o.flow_event();
-            sy.join_flow = !prev_flow && !flow_joined;
-            // the head tile's rows in the same launch: its last writer is stream order at wave 0, else the column
-            // update of the last wave, which then raised a counter behind itself
-            head_flow = g_flow_rows >= 3 && nbm <= 4 && !last && P == 1 && (k == 0 || head_sig);
-            sy.head_flow = head_flow;
-            sy.head_ready = k == 0 ? nullptr : o.sem(k, sem_head_ready, sem_per_wave);
+            // The row-slab kernel (ST_CX) reads its rows of tile (k,k).  Behind another flow wave it follows that wave's
+            // row-slab kernel in stream order and polls the counter the POTRF's first kernel polls (the last SYRK slice
+            // of wave k-1, the tile's last writer).  Otherwise its stream joins the POTRF stream's order by an event --
+            // unless that happened a wave ahead (flow_joined, below) AND this wave polls that counter: without a counter
+            // to poll (the wave before was not counter-linked) the event is the only thing that orders it.
+            sy.join_flow = !prev_flow && (wait_sem == nullptr || !flow_joined);
           }
         }
         // the head tile is this rank's first panel tile only when there is one process row
         const bool head_mine = !last && P == 1;
-        WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine && !head_flow ? ev(k, E_HEAD) : -1,
+        WRC(o.panel(k, lkk, o.winv(par), lkk + g.tile_bytes, cntm, ev_steps, head_mine ? ev(k, E_HEAD) : -1,
                     pipe || pipe_local ? &sy : nullptr, wait_sem, wait_target));
-        if (head_flow) WRC(o.rec(ev(k, E_HEAD), ST_CX));  // (the head tile is complete when the row-slab launch is)
-        if (pipe) panel_target = sy.panel_target;
         if (mr && P > 1 && !last) {
           WRC(o.rec(ev(k, E_LKK), ST_PANEL));
           WRC(diag_send(k, lkk, (const char *)o.winv(par)));
@@ -461,7 +438,7 @@ struct Walker {
         char *tiles = o.tile(il0m, k / Q);
         const char *lkk = lkk_buf[par], *wv = lkk_buf[par] + g.tile_bytes;
         const bool head_mine = !last && g.pr == (k + 1) % P;  // my first tile is L(k+1,k)
-        if (head_mine && sw.head_first && cntm > 1 && o.can_split_trsm()) {
+        if (head_mine && cntm > 1 && o.can_split_trsm()) {
           WRC(o.trsm(k, tiles, 1, lkk, wv, ST_TRSM));
           WRC(o.rec(ev(k, E_HEAD), ST_TRSM));
           WRC(o.trsm(k, tiles + g.tile_bytes, cntm - 1, lkk, wv, ST_TRSM));
@@ -475,10 +452,10 @@ struct Walker {
       // reuse TRSM(k)'s workspace
       const bool by_flags = pipe;
       prev_flow = flow;
-      prev_colsl = colsl;
-      if (flow) ++flow_waves;
+      if (flow) ++flow_waves, ++regimes[R_FLOW];
+      if (pipe || pipe_local) ++regimes[R_PIPE];
       wait_sem = by_flags ? o.sem(k, 3 * nbm, sem_per_wave) : nullptr;
-      wait_target = (mb / 64) * (mb / 64 + 1) / 2 + (colsl ? (cntm - 1) * (mb / 64) * (mb / 64) : 0);
+      wait_target = (mb / 64) * (mb / 64 + 1) / 2;
       // TRSM(k) complete on this rank
       if (in_col) WRC(o.rec(ev(k, mr ? E_TRSM : E_PANEL), ST_TRSM));
       if (own_diag && !by_flags) {
@@ -577,6 +554,8 @@ struct Walker {
           if (o_c1 > 0) ++upd_launches, upd_flops += 2.0 * o_c1 * b3;
         }
         had_pairs = true;
+        ++regimes[R_PAIRED];
+        if (yield) ++regimes[R_YIELD];
         if (mr) WRC(o.rec(ev(k, E_SU), ST_U1));
         continue;
       }
@@ -592,7 +571,7 @@ struct Walker {
       // Give CUs to the next panel's guest workgroups only when that panel is on the critical path, i.e. when
       // this wave's update is not much longer than a panel; otherwise the polling is pure cost.
       const bool yield = (double)(n_r1o + n_r1d + n_r2o + n_r2d) * t_tile < sw.yfac * t_panel;
-      const bool split = yield || sw.split_always;
+      const bool split = yield;
       // the SYRK on (k+1,k+1) needs the head tile L(k+1,k) only; everything else the whole panel
       if (!pipe) {
         if (!split) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
@@ -615,7 +594,7 @@ struct Walker {
       // Counter-linked waves (CHOLMI_PIPE_NEAR): the near half is column k+2 alone, every wave.  The SYRK slices of the
       // NEXT wave (tile (k+2,k+2), on ST_U1) then follow near(k) in stream order instead of waiting for the whole far
       // update of this wave, which started only when this panel was complete: the chain looks two columns ahead.
-      const bool near1 = pipe && sw.pipe_near && split && k + 3 < nt && (double)local_tiles * t_tile < sw.near_fac * t_panel;
+      const bool near1 = pipe && split && k + 3 < nt && (double)local_tiles * t_tile < sw.near_fac * t_panel;
       bool moved = false;
       if (near1) {
         halves = true;
@@ -638,10 +617,9 @@ struct Walker {
       // column k+1 was in U2(k-1)'s range -- or in near(k-1)'s, which precedes this on ST_U1
       if (k > 0 && !prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));
       WRC(o.wt(ST_MAIN, ev(k, E_PANEL)));
-      if (head_flow) WRC(o.wt(ST_MAIN, ev(k, E_HEAD)));
       int timed = 0;  // k_trail_update launches inside this wave's profiling bracket
       // (... of tiles up to 512: with 1024 tiles the form lost 2-4 % -- 256 workgroups per tile, K = 1024 each)
-      const bool u1s = pipe && !colsl && !mr && nbm <= 4 && n_r1o > 0 && n_r1o <= sw.u1_small_max;
+      const bool u1s = pipe && !mr && nbm <= 4 && n_r1o > 0 && n_r1o <= sw.u1_small_max;
       if (split) {
         // the panel chain is (nearly) critical: the diagonal tile (k+1,k+1) alone first, POTRF(k+1)
         // needs nothing else; then the rest of column k+1, which TRSM(k+1) needs
@@ -649,27 +627,16 @@ struct Walker {
           WRC(o.diag_syrk(k, k + 1, ckk, head, ST_U1));
           WRC(o.rec(ev(k, E_U1D), ST_U1));
         }
-        // (in the latency form behind a counter when the panel raised one: no event on the cycle TRSM -> column update -> TRSM)
-        const bool u1c = u1s && panel_target > 0 && !head_flow;
-        if (u1c) WRC(o.gate(ST_U1, o.sem(k, 3 * nbm - 1, sem_per_wave), panel_target));
-        else if (!colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));
-        if (head_flow) WRC(o.wt(ST_U1, ev(k, E_HEAD)));
+        WRC(o.wt(ST_U1, ev(k, E_PANEL)));
         if (halves && prof) WRC(o.rec(ev(k, E_PN0), ST_U1));
         if (u1s) {
-          WRC(o.update_col_small(k, ST_U1, u1c ? o.sem(k, sem_u1_done, sem_per_wave) : nullptr));
-          if (u1c) u1_target_prev = n_r1o * (mb / 64) * (mb / 64);
-        } else if (!colsl) {  // (else: column k+1 went out in slices behind the panel's steps)
+          WRC(o.update_col_small(k, ST_U1));
+        } else {
           WRC(o.update(k, -1, k + 1, k + 2, 1, pk, nullptr, yield, ST_U1));
           if (n_r1o > 0) ++timed;
         }
         WRC(o.rec(ev(k, E_U1R), ST_U1));
-        if (pipe && g_flow_rows >= 3 && nbm <= 4 && k + 2 < nt && flow_ctl_lines(nbm) > 0 && o.flow_ok() && flow_applies(nbm)) {
-          // the next wave's head tile L(k+2,k+1) has its last update: a counter, for the row-slab launch that may solve it
-          WRC(o.signal(ST_U1, o.sem(k + 1, sem_head_ready, sem_per_wave)));
-          head_sig_next = true;
-        }
         if (halves) {
-          if (colsl) WRC(o.wt(ST_U1, ev(k, E_PANEL)));  // (the slices polled; this launch needs the whole panel)
           if (moved && prev_halves) WRC(o.wt(ST_U1, ev(k - 1, E_U2)));  // columns taken over from far(k-1)
           WRC(o.update(k, -1, k + 2, bnd, 3, pk, nullptr, yield, ST_U1));
           if (g.tiles_in(k + 2, bnd) > 0) ++timed;
@@ -704,11 +671,14 @@ struct Walker {
       }
       if (mr) WRC(o.rec(ev(k, E_SU), ST_U1));
       prev_halves = halves;
+      ++regimes[near1 ? R_NEAR1 : halves ? R_HALVES : R_PLAIN];
+      if (yield) ++regimes[R_YIELD];
+      if (u1s) ++regimes[R_U1SMALL];
       upd_launches += timed;
       // algorithmic flops of the launches inside the bracket: GEMM 2 B^3 per off-diagonal tile, SYRK B^3
       // per diagonal tile; the diagonal-tile SYRK of the split form is not a k_trail_update
       upd_flops += (2.0 * n_r2o + n_r2d) * b3;
-      if (!colsl && !u1s) upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
+      if (!u1s) upd_flops += (2.0 * n_r1o + (split ? 0 : n_r1d)) * b3;
     }
     if (open_bracket >= 0 && prof) {
       WRC(o.wt(ST_MAIN, fx(F_COLS)));

@@ -218,6 +218,13 @@ void chol_extract_block(const double *A, int N, int LDA, int B, int bi, int bj, 
  * chol_potrf_tile: total ms and the trailing-update kernel's launch count / ms. */
 int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launches,
                           double *update_flops);
+/* The schedule the last whole-matrix chol_potrf_tile actually ran -- the walker picks a regime per wave from speeds
+ * measured at chol_init (chol_debug_calibration), so two boxes may run two schedules; with this a number can be tied
+ * to its schedule afterwards.  out8: waves that were {0 paired, 1 plain (one far launch), 2 near / far halves,
+ * 3 counter-linked chain, 4 ... with the near column, 5 ... with the tile POTRF as a flow, 6 update yields CUs to the
+ * chain, 7 column k+1 in the latency form}; 0-2 and 4 partition the waves with an update, 3 / 5-7 are attributes.
+ * *nt (may be NULL): the number of waves. */
+int chol_last_potrf_regimes(int *out8, int *nt);
 /* 1 = bracket the trailing-update launches of every wave (pair of waves) with HIP events
  * on the stream the big launch runs on; the wait that closes a bracket joins launches the
  * next wave's big launch depends on anyway, so no dependency is added (walker.h) -- what
@@ -226,9 +233,8 @@ int chol_last_potrf_stats(double *total_ms, double *update_ms, int *update_launc
 int chol_set_profiling(int on);
 
 /* Diagnostic: time the trailing-update launch of wave k alone (best of `reps`), on whatever
- * data the descriptor holds (the matrix is modified).  ablate: 0 = the production kernel; other values
- * select the ablation twin (bit 0 no global loads, 1 no LDS fragment reads, 2 no C read, 3 no barriers;
- * timing only), which exists in diagnostic builds only (make DIAG=1; CHOL_ERR_NOT_SUPPORTED otherwise). */
+ * data the descriptor holds (the matrix is modified).  ablate must be 0 (the ablation twin of rounds 1-4 left the
+ * library in round 5: CHOL_ERR_NOT_SUPPORTED). */
 int chol_bench_update(chol_desc_t *desc, int k, int ablate, int reps, double *ms, double *flops);
 
 /* Diagnostic: enable = 1 starts recording, per diagonal-block workgroup, 8 words of 100 MHz
@@ -265,8 +271,7 @@ int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, doubl
  * [TFLOP/s], fp64 128 x 128 diagonal-block step alone [us], the same for fp32; out8[4..7] = the derived
  * update rate inside the DAG [TFLOP/s] and panel-chain step [us] per dtype that the thresholds use. */
 int chol_debug_calibration(double *out8);
-/* Name of the trailing-update kernel launched for `dtype` under the current CHOLMI_VARIANT / CHOLMI_F32_W8
- * switches, as a profiler prints it (bench.py's roofline.kernel). */
+/* Name of the trailing-update kernel launched for `dtype`, as a profiler prints it (bench.py's roofline.kernel). */
 int chol_debug_update_kernel(int dtype, char *buf, int buflen);
 /* 1 if chain-bound waves can use device-side counters (chol_init's probe found the panel streams on independent
  * hardware queues, and no device-side wait has timed out since), 0 if every dependency is a stream event -- e.g.

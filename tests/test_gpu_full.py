@@ -421,8 +421,7 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
         assert np.linalg.norm(U.T @ U - A) / np.linalg.norm(A) <= (1e-13 if dt == "f64" else 5e-5)
 
 
-@pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"},
-                                 {"CHOLMI_PAIR_MAX_MB": "0", "CHOLMI_VARIANT": "0"}, {"CHOLMI_TRSM_FUSED_MIN": "1"},
+@pytest.mark.parametrize("env", [{"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "1000"},
                                  # pairs entered behind a wave launched as near / far halves (wave 0 stays plain), left at the end
                                  {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"},
                                  # the chain-bound form (device-side counters): off (events only), from the
@@ -435,12 +434,9 @@ def test_potrs_and_posv_against_numpy(cham, orc, N, B, nrhs, dt):
                                  # counters: every grid behind a gate kernel / every grid polling itself
                                  {"CHOLMI_POLL_MAX_WGS": "0"}, {"CHOLMI_POLL_MAX_WGS": "100000"},
                                  # counter-linked waves from the first one on: without the near column (column k+2 as a launch
-                                 # of its own) and the latency form of column k+1; with them (the default) and that launch
-                                 # behind counters instead of events; column slices on top
-                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_PIPE_NEAR": "0", "CHOLMI_U1_SMALL": "0"},
-                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64",
-                                  "CHOLMI_U1_COUNTERS": "1"},
-                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_COL_SLICES": "1"},
+                                 # of its own) and the latency form of column k+1; with both for every wave
+                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "0", "CHOLMI_U1_SMALL": "0"},
+                                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64"},
                                  # ... entered behind waves launched as wider near / far halves
                                  {"CHOLMI_PIPE_FACTOR": "0.3", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"}])
 def test_walker_schedule_variants_match_the_oracle(env, orc):
@@ -483,17 +479,12 @@ FLOW_ALL = {"CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PA
     (3072, 512, FLOW_ALL),                                         # four 128-blocks per tile, every wave in flow form
     (3072, 384, FLOW_ALL),                                         # three
     (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_FENCES="1")),           # ... with release / acquire fences around every hand-off
-    (4096, 1024, dict(FLOW_ALL, CHOLMI_FLOW_MAX_NBM="8")),         # eight blocks per tile (off by default: measured slower)
-    (2048, 256, dict(FLOW_ALL, CHOLMI_FLOW_MIN_NBM="2")),          # two
+    (4096, 1024, dict(FLOW_ALL, CHOLMI_FLOW_NBM="2:8")),           # eight blocks per tile (off by default: measured slower)
+    (2048, 256, dict(FLOW_ALL, CHOLMI_FLOW_NBM="2:4")),            # two
     (4096, 512, {"CHOLMI_FLOW_FACTOR": "0.05"}),                   # entered late: event-linked, counter-linked, then flow waves
     (4096, 512, {}),                                               # the default rule: chain-bound from wave 0 on -> flow
-    # the streaming row slabs (k_flow_rows2; measured alternatives, off by default): the diagonal tile's rows; the head
-    # tile's too; the whole panel's; with column slices behind them; three blocks per tile
-    (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="2", CHOLMI_NEAR_FACTOR="100")),
-    (3072, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="3", CHOLMI_NEAR_FACTOR="100")),
-    (4096, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_NEAR_FACTOR="100")),
-    (4096, 512, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_COL_SLICES="1", CHOLMI_NEAR_FACTOR="100")),
-    (3072, 384, dict(FLOW_ALL, CHOLMI_FLOW_ROWS="4", CHOLMI_FLOW_PANEL_MAX="3")),
+    # flow waves behind PAIRED waves: no counter to poll, the row-slab kernel is ordered by its join event alone (advisor, round 4)
+    (3584, 512, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_FLOW_FACTOR": "0.1"}),
 ])
 def test_flow_form_of_the_tile_potrf_matches_the_oracle(N, B, env, orc):
     """k_flow_factor / k_flow_rows (round 4): the tile POTRF of a counter-linked wave as two persistent launches whose

@@ -302,7 +302,7 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
         # both ship the eight-wave update (two waves of a workgroup per SIMD)
         upd, per_simd = (find("k_trail_update_w8IdLi3E"), 2) if t == "d" else (find("k_trail_update_w8f"), 2)
         assert 2 * per_simd * upd["vgprs"] <= 512 and 2 * upd["lds"] <= 160 * 1024
-        for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_updateI%sE",
+        for guest in ("k_potrf_diagI%sE", "k_panel_solveI%sE", "k_panel_updateI%sE", "k_intile_stepI%sE",
                       "k_solve_smallI%sE", "k_small_updateI%sE"):
             g = find(guest % t)
             assert g["vgprs"] + per_simd * upd["vgprs"] <= 512, (guest % t, g, upd)
@@ -313,10 +313,6 @@ def test_guest_kernels_fit_on_a_cu_beside_a_resident_update_workgroup():
     for t in ("d", "f"):
         ff, fr = find("k_flow_factorI%sE" % t), find("k_flow_rowsI%sE" % t)
         assert ff["vgprs"] <= 512 and fr["vgprs"] <= 512 and ff["lds"] + fr["lds"] <= 160 * 1024
-    # the four-wave kernels stay selectable (CHOLMI_VARIANT=0, CHOLMI_F32_W8=0): same budget
-    for name, diag in (("k_trail_updateIdLb1ELb0E", "k_potrf_diagIdE"), ("k_trail_updateIfLb1ELb0E", "k_potrf_diagIfE")):
-        upd = find(name)
-        assert 2 * upd["vgprs"] <= 512 and find(diag)["vgprs"] + upd["vgprs"] <= 512
 
 
 def test_v3_long_option_front_end_argument_checks():

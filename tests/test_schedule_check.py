@@ -1,7 +1,7 @@
 """The wave walker's dependencies, checked without a GPU (csrc/sched_check.hip, chol_debug_schedule_check): the walker
 runs over an engine that records every launch with the tiles it reads and writes, every event record / wait and every
 counter edge, and any two launches that touch the same tile (or block-inverse workspace), one of them writing, must be
-ordered.  The schedule is picked per wave from measured speeds and a dozen CHOLMI_* switches:
+ordered.  The schedule is picked per wave from measured speeds and eight threshold switches:
 here every regime is forced at many sizes.  A missing dependency shows on the GPU as a rare wrong digit at best; here
 it is a deterministic finding that names the two launches."""
 import ctypes as C
@@ -25,21 +25,21 @@ def check(nt, mb, t_tile, t_panel, profiling=0, grid=(1, 1), rank=0):
 
 SWITCHES = [
     {},
-    {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"}, {"CHOLMI_PAIR_MAX_MB": "0"},
+    {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "1000"},
     {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"},
-    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_PIPE_FACTOR": "0.02"}, {"CHOLMI_SYRK_PIPE": "0"},
+    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_PIPE_FACTOR": "0.02"}, {"CHOLMI_PIPE_FACTOR": "0"},
     {"CHOLMI_PIPE_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
-    {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_SPLIT_U1": "1"}, {"CHOLMI_YIELD_FACTOR": "0"},
-    # round 4: the near column, the latency form of column k+1 (also behind counters), column slices, the flow form late / never / always
-    {"CHOLMI_PIPE_NEAR": "0"}, {"CHOLMI_U1_SMALL": "0"}, {"CHOLMI_PIPE_NEAR": "0", "CHOLMI_U1_SMALL": "0"},
-    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64", "CHOLMI_U1_COUNTERS": "1"},
-    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_COL_SLICES": "1"},
+    {"CHOLMI_HALVES_MAX_ROUNDS": "0", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_YIELD_FACTOR": "0"}, {"CHOLMI_YIELD_FACTOR": "1000"},
+    # the near column, the latency form of column k+1, the flow form late / never / always
+    {"CHOLMI_NEAR_FACTOR": "0"}, {"CHOLMI_U1_SMALL": "0"}, {"CHOLMI_NEAR_FACTOR": "0", "CHOLMI_U1_SMALL": "0"},
+    {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_U1_SMALL": "64"},
     {"CHOLMI_PIPE_FACTOR": "0.3", "CHOLMI_NEAR_FACTOR": "100", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PAIR_FACTOR": "1000"},
-    {"CHOLMI_NEAR_FACTOR": "0.3"}, {"CHOLMI_U1_COUNTERS": "1"}, {"CHOLMI_COL_SLICES": "1"},
+    {"CHOLMI_NEAR_FACTOR": "0.3"},
     {"CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_FLOW_FACTOR": "0.05"},
     {"CHOLMI_FLOW_RUN_FACTOR": "0"}, {"CHOLMI_FLOW_RUN_FACTOR": "100"},
-    {"CHOLMI_FLOW_ROWS": "2"}, {"CHOLMI_FLOW_ROWS": "3"}, {"CHOLMI_FLOW_ROWS": "4", "CHOLMI_COL_SLICES": "1"},
-    {"CHOLMI_FLOW_ROWS": "4", "CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000", "CHOLMI_NEAR_FACTOR": "100"},
+    # flow-form waves BEHIND waves that are not counter-linked (pairs everywhere they fit, the flow wherever it fits): the
+    # row-slab kernel has no counter to poll there and must join the POTRF stream by its event (advisor, round 4)
+    {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_FLOW_FACTOR": "0.1"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_FLOW_FACTOR": "100", "CHOLMI_PIPE_FACTOR": "100"},
 ]
 
 
@@ -91,9 +91,9 @@ def test_the_checker_sees_a_missing_dependency(nt, mb, t_tile, t_panel, monkeypa
     assert seen >= 0.4 * nwaits, (seen, nwaits)
 
 
-GRID_SWITCHES = [{}, {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_PAIR_START": "0"}, {"CHOLMI_PAIR_MAX_MB": "0"},
-                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_SYRK_PIPE": "0"}, {"CHOLMI_HEAD_FIRST": "0"},
-                 {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_SPLIT_U1": "1"}]
+GRID_SWITCHES = [{}, {"CHOLMI_PAIR_FACTOR": "0"}, {"CHOLMI_PAIR_FACTOR": "1000"},
+                 {"CHOLMI_PIPE_FACTOR": "100", "CHOLMI_PAIR_FACTOR": "1000"}, {"CHOLMI_PIPE_FACTOR": "0"},
+                 {"CHOLMI_PAIR_FACTOR": "0", "CHOLMI_HALVES_MAX_ROUNDS": "1000", "CHOLMI_PIPE_FACTOR": "0"}, {"CHOLMI_YIELD_FACTOR": "1000"}]
 
 
 @pytest.mark.parametrize("env", GRID_SWITCHES, ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
@@ -127,3 +127,23 @@ def test_the_checker_sees_a_missing_dependency_on_a_grid(grid, rank, monkeypatch
     # (the rest are implied by other paths: the start / join waits, the panel buffers' last readers -- wave k's panel needs every
     # earlier update of its column anyway -- and the waits that keep POTRF(k+2) off block inverses that are still travelling)
     assert seen >= 0.4 * cnt[1], (seen, cnt[1])
+
+
+def test_a_flow_wave_behind_a_paired_wave_is_ordered_by_its_join_event(monkeypatch):
+    """Advisor's finding of round 4 (walker.h: join_flow): PAIR_FACTOR=0 + FLOW_FACTOR=0.1 at nt = 7, tile 512 -- wave 0 is
+    counter-linked and pre-joins the flow stream, waves 1-4 go in pairs, wave 5 is a flow wave with no counter to poll.  Its
+    row-slab kernel (ST_CX) reads rows of tile (5,5) that the paired updates wrote: the join event is the only thing that
+    orders it, and the checker -- which now records that kernel as a launch of its own on ST_CX -- must say so when the
+    join is dropped."""
+    monkeypatch.setenv("CHOLMI_PAIR_FACTOR", "0")
+    monkeypatch.setenv("CHOLMI_FLOW_FACTOR", "0.1")
+    n, rep, cnt = check(7, 512, T512, P512)
+    assert n == 0 and cnt[3] >= 1, rep
+    joins = []
+    for i in range(cnt[1]):
+        monkeypatch.setenv("CHOLMI_CHECK_DROP_WAIT", str(i))
+        n, rep, _ = check(7, 512, T512, P512)
+        if "flow stream's join" in rep:
+            joins.append((i, n, rep))
+    assert joins, "no flow wave joined its stream by an event in this schedule"
+    assert all(n > 0 and "row slabs" in rep for _, n, rep in joins), joins
