@@ -134,6 +134,8 @@ def worker_path(N: int, B: int) -> dict:
     ref = np.linalg.cholesky(A[:B, :B])
     return {"N": N, "tile": B, "tasks": n, "seconds": round(best.seconds, 4), "tflops": round(N ** 3 / 3.0 / best.seconds / 1e12, 2),
             "us_per_task": round(best.seconds / n * 1e6, 2), "best_of": 3,
+            # when the client's last submission returned: the host side of the path (the rest is the GPU catching up)
+            "submit_seconds": round(best.submit_seconds, 4), "host_us_per_task": round(best.submit_seconds / n * 1e6, 2),
             "tile00_max_rel_err": float(np.abs(L00 - ref).max() / np.abs(ref).max()),
             "what": "client.run_cholesky_dag(device_results=True, batched=True): wave-level execution behind the task API"}
 

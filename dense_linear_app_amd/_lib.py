@@ -88,6 +88,9 @@ def lib() -> C.CDLL:
         "chol_sync": ([], i),
         "chol_potrf_batch": ([i, i, i, vp, vp, vp, C.POINTER(i), i], i),
         "chol_batch_info": ([i, C.POINTER(i)], i),
+        "chol_batch_stats": ([C.POINTER(C.c_longlong)], i),
+        "chol_batch_mark": ([C.POINTER(C.c_ulonglong)], i),
+        "chol_batch_wait": ([C.POINTER(C.c_ulonglong)], i),
         "chol_debug_calibration": ([C.POINTER(d)], i),
         "chol_debug_update_kernel": ([i, C.c_char_p, i], i),
         "chol_debug_device_counters": ([], i),

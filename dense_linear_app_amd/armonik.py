@@ -203,6 +203,10 @@ class TaskHandler:
     def first_expected_result(self) -> str:
         return self._task.expected_output_keys[0]
 
+    def priority(self) -> int:
+        """getTaskOptions().priority (C2:335) without the copy."""
+        return self._task.options.priority
+
     def getSessionId(self) -> str:
         return self._session
 

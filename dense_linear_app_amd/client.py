@@ -175,6 +175,7 @@ class DagResult:
     task_counts: Dict[str, int]
     seconds: float
     plane: ak.ControlPlane = field(repr=False, default=None)
+    submit_seconds: float = 0.0  # wave-level client: when the last submission returned (the rest of `seconds` is the GPU catching up)
 
     def tile(self, i: int, j: int) -> np.ndarray:
         data = ak.ResultsClient(self.plane).download_result_data(self.session_id, self.latest[block_id_from_ij(i, j)])
@@ -255,18 +256,28 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
         eventsClient.wait_for_result_availability(session_id, [output_id])
         return output_id
 
-    def submit_batch(items: List[tuple]) -> List[str]:
-        """items: (payload_json, data_deps).  One metadata call, one submission, one wait."""
+    names_cache: Dict[int, tuple] = {}
+    opts_by_priority: Dict[int, ak.TaskOptions] = {}
+
+    def submit_batch(items: List[tuple], priority: int = 1) -> List[str]:
+        """items: (payload_json, data_deps).  One metadata call, one submission, one wait.  priority: TaskOptions.priority of
+        the submission (C2:335 sets 1 for everything; the wave-level client raises it for the tasks of the panel chain)."""
         if not items:
             return []
         m = len(items)
-        onames, pnames = [f"output/{q}" for q in range(m)], [f"payload/{q}" for q in range(m)]
+        names = names_cache.get(m)
+        if names is None:
+            names = names_cache[m] = ([f"output/{q}" for q in range(m)], [f"payload/{q}" for q in range(m)])
+        onames, pnames = names
         ids = resultsClient.create_results_metadata(session_id, onames + pnames)
         outs, pids = [ids[x] for x in onames], [ids[x] for x in pnames]
         resultsClient.upload_results_data(session_id, {pid: it[0] for pid, it in zip(pids, items)})  # one call, not m
         tcs = [ak.TaskCreation(pid, [oid], sorted(set(it[1]))) for pid, oid, it in zip(pids, outs, items)]
-        opts = taskOptions.copy()
-        opts.partition_id = PARTITION
+        opts = opts_by_priority.get(priority)
+        if opts is None:
+            opts = opts_by_priority[priority] = taskOptions.copy()
+            opts.partition_id = PARTITION
+            opts.priority = priority
         tasksClient.submit_tasks(session_id, tcs, opts)
         eventsClient.wait_for_result_availability(session_id, outs)
         return outs
@@ -292,7 +303,11 @@ def run_cholesky_dag(N: int, B: int, plane: Optional[ak.ControlPlane] = None, wo
 
 def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane, eventsClient, device_results, t0,
                        resultsClient=None, worker=None):
-    """C2:506-565, one submission per phase of a wave."""
+    """C2:506-565, one submission per phase of a wave: POTRF; all TRSM; the updates of column k+1 (what
+    POTRF(k+1) and TRSM(k+1) depend on); the other updates.  The first three go out with TaskOptions.priority 2 -- the
+    tasks of the panel chain -- so that a worker that executes dependency-driven (worker.ExecuteBatch over the
+    library's two-stream executor) runs wave k+1's chain beside wave k's bulk update.  Nothing waits for the GPU here:
+    a submission returns when its tasks are enqueued, their outputs are ordered by what reads them."""
     if True:
         # (the same payload texts as make_payload -- json.dumps with compact separators -- written directly: the ids are
         # the control plane's own hex ids, nothing in them needs escaping; asserted once below)
@@ -300,54 +315,69 @@ def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane
         assert make_payload("GEMM", ["a", "b", "c"], B) == f'{{"op":"GEMM","B":{int(B)},"inC":"a","inAi":"b","inAj":"c"}}'
         Bi = int(B)
         # Results are write-once, so every task adds a tile version; with the tiles resident in HBM the superseded
-        # versions have to go, or N=65536 / tile 1024 would hold 45 760 x 8 MiB.  They are released in bulk once
-        # RETIRE_BYTES of them have piled up, behind a wait for the launches that may still read them (chol_sync:
-        # the host is then idle until the GPU has caught up -- rare: never below ~12 000 tile-MiB of versions).
+        # versions have to go, or N=65536 / tile 1024 would hold 45 760 x 8 MiB.  The versions wave k supersedes are read
+        # by wave k's tasks only, so they may go once everything enqueued up to the end of wave k has run: the worker takes
+        # a MARK there (chol_batch_mark), and once RETIRE_BYTES of versions have piled up the oldest waves' versions are
+        # released behind a wait for THEIR mark (chol_batch_wait) -- the GPU keeps running the waves submitted since; a
+        # full drain here (round 4: chol_sync) left it idle for as long as the host needs to submit the next wave.
+        from collections import deque
+
         retire_limit = int(os.environ.get("CHOLESKY_RETIRE_BYTES", str(24 << 30)))
-        retired, retired_bytes, tile_bytes = [], 0, 8 * Bi * Bi
-        can_retire = device_results and resultsClient is not None and hasattr(worker, "flush")
+        retire_q, retired_bytes, tile_bytes = deque(), 0, 8 * Bi * Bi
+        can_retire = device_results and resultsClient is not None and hasattr(worker, "mark")
         for k in range(Nb):
-            if can_retire and retired_bytes > retire_limit:
-                if plane.flush_quiet():  # (a failed POTRF found on the way: leave everything for the final flush to report)
-                    resultsClient.delete_results_data(session_id, retired)
-                    retired, retired_bytes = [], 0
-                else:
-                    can_retire = False
+            while can_retire and retired_bytes > retire_limit and retire_q:
+                mark, ids, nbytes = retire_q.popleft()
+                worker.wait_mark(mark)
+                resultsClient.delete_results_data(session_id, ids)
+                retired_bytes -= nbytes
             kk = bid[k][k]
             if can_retire:
-                retired.append(latest[kk])
-                retired.extend(latest[bid[i][j]] for i in range(k + 1, Nb) for j in range(k, i + 1))
-                retired_bytes += tile_bytes * (1 + (Nb - k - 1) * (Nb - k + 2) // 2)
-            latest[kk] = submit_batch([(make_payload("POTRF", [latest[kk]], B), [latest[kk]])])[0]
+                gone = [latest[kk]]
+                gone.extend(latest[bid[i][j]] for i in range(k + 1, Nb) for j in range(k, i + 1))
+            latest[kk] = submit_batch([(make_payload("POTRF", [latest[kk]], B), [latest[kk]])], 2)[0]
             counts["POTRF"] += 1
             Lkk = latest[kk]
             rows = range(k + 1, Nb)
             ins = [latest[bid[i][k]] for i in rows]
-            outs = submit_batch([(f'{{"op":"TRSM","B":{Bi},"inL":"{Lkk}","inA":"{a}"}}', [Lkk, a]) for a in ins])
+            outs = submit_batch([(f'{{"op":"TRSM","B":{Bi},"inL":"{Lkk}","inA":"{a}"}}', [Lkk, a]) for a in ins], 2)
             for i, o in zip(rows, outs):
                 latest[bid[i][k]] = o
             counts["TRSM"] += len(outs)
-            items, keys = [], []
+            # column k+1 first and apart (the chain's tasks), then the rest of the wave's update
+            k1 = k + 1
+            items1, keys1, items, keys = [], [], [], []
             for i, Aik in zip(rows, outs):
                 row = bid[i]
-                for j in range(k + 1, i):
+                if i > k1:
+                    Cij, Ajk = latest[row[k1]], outs[0]
+                    items1.append((f'{{"op":"GEMM","B":{Bi},"inC":"{Cij}","inAi":"{Aik}","inAj":"{Ajk}"}}', [Cij, Aik, Ajk]))
+                    keys1.append(row[k1])
+                for j in range(k + 2, i):
                     Cij, Ajk = latest[row[j]], latest[bid[j][k]]
                     items.append((f'{{"op":"GEMM","B":{Bi},"inC":"{Cij}","inAi":"{Aik}","inAj":"{Ajk}"}}', [Cij, Aik, Ajk]))
                     keys.append(row[j])
                 Cii = latest[row[i]]
-                items.append((f'{{"op":"SYRK","B":{Bi},"inC":"{Cii}","inA":"{Aik}"}}', [Cii, Aik]))
-                keys.append(row[i])
+                (items1 if i == k1 else items).append((f'{{"op":"SYRK","B":{Bi},"inC":"{Cii}","inA":"{Aik}"}}', [Cii, Aik]))
+                (keys1 if i == k1 else keys).append(row[i])
                 counts["GEMM"] += i - k - 1
                 counts["SYRK"] += 1
+            for key, o in zip(keys1, submit_batch(items1, 2)):
+                latest[key] = o
             for key, o in zip(keys, submit_batch(items)):
                 latest[key] = o
+            if can_retire:
+                nbytes = tile_bytes * len(gone)
+                retire_q.append((worker.mark(), gone, nbytes))
+                retired_bytes += nbytes
+        t_sub = time.perf_counter() - t0
         if device_results:
             # grouped launches are asynchronous on the library's stream: the run ends when they have; a tile that
             # turned out not to be positive definite fails its POTRF task now, and the wait below raises as the
             # blocking client's wait on that task's output does (C2:499)
             plane.flush()
             eventsClient.wait_for_result_availability(session_id, list(latest.values()))
-        return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane)
+        return DagResult(N, B, Nb, session_id, latest, counts, time.perf_counter() - t0, plane, t_sub)
 
 
 def _run_waves_serial(N, B, Nb, session_id, latest, counts, submit_one, plane, verbose, log, t0):

@@ -10,8 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/cholmi.h"
@@ -49,6 +51,46 @@ struct Ctx {
   unsigned binfo_next = 0;
   std::string last_error;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// The executor behind the grouped launches of the task API (chol_tile_batch / chol_potrf_batch): dependency-driven on
+// TWO streams.  The reference's tasks name their data dependencies (C2:489-499), so a scheduler may start POTRF(k+1)
+// as soon as SYRK(k+1,k+1,k) is done; here the batches of the panel chain (POTRF, TRSM, and the updates the caller
+// marks CHOL_BATCH_URGENT: column k+1) go to the high-priority chain stream, all other updates to the bulk stream, and
+// what orders two batches is what they read and write: every output tile pointer is remembered with the (stream,
+// sequence number) of the batch that writes it; a batch that reads a tile written on the OTHER stream waits for that
+// batch's event first (one wait per batch at most: the newest such producer).  Results are write-once buffers (a
+// batch's outputs are fresh memory), so there is no write-after-read edge to track; chol_sync() drains both streams
+// and forgets everything.  Walker-style overlap follows: wave k+1's chain runs beside wave k's bulk update.
+// ---------------------------------------------------------------------------------------------------------------
+struct TaskExec {
+  enum { CHAIN = 0, BULK = 1, EVPOOL = 64 };
+  bool ready = false, dirty = false;
+  hipStream_t st[2] = {nullptr, nullptr};
+  unsigned long long seq[2] = {0, 0}, done[2] = {0, 0};
+  unsigned long long waited[2][2] = {{0, 0}, {0, 0}};  // [consumer][producer]: newest batch of `producer` the consumer stream already follows
+  hipEvent_t ev[2][EVPOOL] = {};
+  unsigned long long ev_seq[2][EVPOOL] = {};
+  struct Prod {
+    int stream;
+    unsigned long long seq;
+  };
+  std::unordered_map<const void *, Prod> prod;
+  // pointer lists of the batches: a pinned host ring mirrored into a device ring, one slice per batch
+  char *h_ring = nullptr, *d_ring = nullptr;
+  size_t ring_bytes = (size_t)16 << 20, ring_pos = 0;
+  struct Slice {
+    size_t begin, end;
+    int stream;
+    unsigned long long seq;
+  };
+  std::deque<Slice> slices;
+  void *winv = nullptr;  // block inverses of the POTRF batches (two sets by parity of the POTRF count), chain stream only
+  unsigned long long npotrf = 0;
+  long long batches[2] = {0, 0}, cross_waits = 0;  // statistics: batches per stream, event waits between them
+};
+TaskExec tx;
+int tx_quiesce();
 Ctx g;
 std::recursive_mutex g_mu;     // one ABI call at a time on the context
 std::mutex g_err_mu; // chol_last_error's buffer
@@ -121,6 +163,126 @@ int remember_winv(const void *ptr, unsigned long long version, int mb, int dtype
 }
 void forget_winv(const void *ptr) {
   if (g.wc_ptr == ptr) g.wc_ptr = nullptr, g.wc_version = 0;
+}
+
+// ---- the task executor (TaskExec above) ------------------------------------------------------------------------
+int tx_init() {
+  if (tx.ready) return 0;
+  tx.st[TaskExec::CHAIN] = g.r.st[ST_PANEL];
+  tx.st[TaskExec::BULK] = g.r.st[ST_MAIN];
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < TaskExec::EVPOOL; ++i) HIPCHECK(hipEventCreateWithFlags(&tx.ev[s][i], hipEventDisableTiming));
+  HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&tx.h_ring), tx.ring_bytes, hipHostMallocDefault));
+  HIPCHECK(hipMalloc(reinterpret_cast<void **>(&tx.d_ring), tx.ring_bytes));
+  HIPCHECK(hipMalloc(&tx.winv, 2 * g.r.winv_bytes));
+  tx.ready = true;
+  return 0;
+}
+void tx_destroy() {
+  if (!tx.ready) return;
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < TaskExec::EVPOOL; ++i)
+      if (tx.ev[s][i]) (void)hipEventDestroy(tx.ev[s][i]);
+  (void)hipHostFree(tx.h_ring);
+  (void)hipFree(tx.d_ring);
+  (void)hipFree(tx.winv);
+  tx = TaskExec();
+}
+// everything the executor has enqueued is complete afterwards; nothing is remembered
+int tx_quiesce() {
+  if (!tx.ready || !tx.dirty) return 0;
+  HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));
+  HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::BULK]));
+  for (int s = 0; s < 2; ++s) {
+    tx.done[s] = tx.seq[s];
+    tx.waited[s][0] = tx.waited[s][1] = 0;
+  }
+  tx.prod.clear();
+  tx.slices.clear();
+  tx.dirty = false;
+  return 0;
+}
+// (defined further down; the cached block inverses of the executor die with the context)
+
+// the host waits until batch `seq` of `stream` has run (an event of the pool that was recorded at or after it)
+int tx_wait_host(int stream, unsigned long long seq) {
+  if (tx.done[stream] >= seq) return 0;
+  const int slot = (int)(seq % TaskExec::EVPOOL);
+  HIPCHECK(hipEventSynchronize(tx.ev[stream][slot]));
+  tx.done[stream] = std::max(tx.done[stream], tx.ev_seq[stream][slot]);
+  return 0;
+}
+// a slice of the pointer-list rings (same offset on the host and on the device side)
+int tx_take(size_t bytes, size_t *off) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > tx.ring_bytes) return fail(CHOL_ERR_NOT_SUPPORTED, "tile batch: more tasks than one grouped launch takes (split the batch)");
+  if (tx.ring_pos + bytes > tx.ring_bytes) tx.ring_pos = 0;
+  const size_t b = tx.ring_pos, e = b + bytes;
+  for (size_t i = 0; i < tx.slices.size();) {  // slices of earlier batches under the new one: their batches must have run
+    const TaskExec::Slice sl = tx.slices[i];
+    const bool over = sl.begin < e && b < sl.end;
+    if (over) {
+      if (int rc = tx_wait_host(sl.stream, sl.seq)) return rc;
+    }
+    if (over || tx.done[sl.stream] >= sl.seq) tx.slices.erase(tx.slices.begin() + (long)i);
+    else ++i;
+  }
+  tx.ring_pos = e;
+  *off = b;
+  return 0;
+}
+// stream X follows the batches (of the other stream) that write the n tiles of each of the `nl` pointer lists
+int tx_follow(int X, const void *const *const *lists, int nl, int n) {
+  const int Y = 1 - X;
+  unsigned long long need = 0;
+  if (!tx.prod.empty())
+    for (int l = 0; l < nl; ++l) {
+      if (!lists[l]) continue;
+      for (int t = 0; t < n; ++t) {
+        const void *p = lists[l][t];
+        if (!p) continue;
+        auto it = tx.prod.find(p);
+        if (it != tx.prod.end() && it->second.stream == Y && it->second.seq > need) need = it->second.seq;
+      }
+    }
+  if (need > tx.waited[X][Y]) {
+    if (tx.done[Y] < need) {
+      HIPCHECK(hipStreamWaitEvent(tx.st[X], tx.ev[Y][need % TaskExec::EVPOOL], 0));
+      ++tx.cross_waits;
+    }
+    tx.waited[X][Y] = need;
+  }
+  return 0;
+}
+// the batch just enqueued on X: its event, its ring slice, the tiles it writes
+int tx_commit(int X, void *const *outs, int n, size_t slice_b, size_t slice_e) {
+  const unsigned long long seq = ++tx.seq[X];
+  const int slot = (int)(seq % TaskExec::EVPOOL);
+  HIPCHECK(hipEventRecord(tx.ev[X][slot], tx.st[X]));
+  tx.ev_seq[X][slot] = seq;
+  for (int t = 0; t < n; ++t) tx.prod[outs[t]] = TaskExec::Prod{X, seq};
+  if (slice_e > slice_b) tx.slices.push_back(TaskExec::Slice{slice_b, slice_e, X, seq});
+  ++tx.batches[X];
+  tx.dirty = true;
+  return 0;
+}
+
+// block inverses of the executor's POTRF / TRSM batches: two sets, alternating, all on the chain stream; the last one
+// written is remembered under (tile pointer, content tag) for the TRSM batch that names the same L
+void *tx_winv_set() { return reinterpret_cast<char *>(tx.winv) + (size_t)(tx.npotrf++ & 1) * g.r.winv_bytes; }
+struct TxWinv {
+  const void *ptr = nullptr, *set = nullptr;
+  unsigned long long version = 0;
+  int mb = 0, dtype = 0;
+} tx_wc;
+const void *tx_cached_winv(const void *ptr, unsigned long long version, int mb, int dtype) {
+  if (!version || tx_wc.ptr != ptr || tx_wc.version != version || tx_wc.mb != mb || tx_wc.dtype != dtype) return nullptr;
+  return tx_wc.set;
+}
+void tx_remember_winv(const void *ptr, unsigned long long version, int mb, int dtype, const void *set) {
+  tx_wc = TxWinv();
+  if (!version) return;
+  tx_wc.ptr = ptr, tx_wc.version = version, tx_wc.mb = mb, tx_wc.dtype = dtype, tx_wc.set = set;
 }
 
 int ensure_events(size_t n) {
@@ -266,6 +428,7 @@ struct ViewArg {
 template <typename F>
 static int with_views(std::initializer_list<ViewArg> views, F &&body) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (int rc = tx_quiesce()) return rc;  // (the synchronous calls run on ST_MAIN alone: nothing of the task executor may be in flight)
   for (const ViewArg &v : views)
     if (v.d && v.d->user_mat) {
       const int rc = view_sync(v.d, true);
@@ -785,6 +948,7 @@ int chol_finalize(void) {
   g.wc_winv = nullptr;
   if (g.d_binfo) (void)hipFree(g.d_binfo);
   g.d_binfo = nullptr;
+  tx_destroy();
   g.wc_ptr = nullptr;
   g.wc_version = 0;
   (void)hipFree(g.d_acc);
@@ -957,81 +1121,103 @@ int chol_sync(void) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "chol_sync before chol_init");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
-  return 0;
+  return tx_quiesce();
 }
 
 }  // extern "C"
 
 // ---------------------------------------------------------------- the tasks of one op class in one grouped launch
+// (the executor: TaskExec / tx_* above)
 template <typename T>
 static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a, const void *const *b,
-                           void *const *c_out, const unsigned long long *a_versions) {
-  hipStream_t s = g.r.st[ST_MAIN];
-  const size_t tb = (size_t)mb * mb * sizeof(T);
-  // device copies of the four pointer lists (stream-ordered behind the kernels still reading the last batch's)
-  const size_t lb = (size_t)n * sizeof(void *);
-  int rc = ensure_stage(0, 4 * lb);
+                           void *const *c_out, const unsigned long long *a_versions, int flags) {
+  int rc = tx_init();
   if (rc) return rc;
-  char *dl = reinterpret_cast<char *>(g.stage[0]);
-  const void *const *lists[4] = {c_in, a, b ? b : a, (const void *const *)c_out};
-  std::vector<const void *> packed((size_t)4 * n);
-  for (int l = 0; l < 4; ++l) memcpy(packed.data() + (size_t)l * n, lists[l], lb);
-  HIPCHECK(hipMemcpyAsync(dl, packed.data(), 4 * lb, hipMemcpyHostToDevice, s));
+  const bool update = op != CHOL_BATCH_TRSM;
+  const int X = (!update || (flags & CHOL_BATCH_URGENT)) ? TaskExec::CHAIN : TaskExec::BULK;
+  hipStream_t s = tx.st[X];
+  const size_t tb = (size_t)mb * mb * sizeof(T), lb = (size_t)n * sizeof(void *);
+  // the four pointer lists: pinned host slice -> device slice, in stream order ahead of the kernels that read them
+  size_t off = 0;
+  rc = tx_take(4 * lb, &off);
+  if (rc) return rc;
+  char *hl = tx.h_ring + off, *dl = tx.d_ring + off;
+  memcpy(hl, c_in, lb);
+  memcpy(hl + lb, a, lb);
+  if (op == CHOL_BATCH_SYRK || !b) memset(hl + 2 * lb, 0, lb);  // (null: a SYRK task)
+  else memcpy(hl + 2 * lb, b, lb);
+  memcpy(hl + 3 * lb, c_out, lb);
+  const void *const *ins[3] = {c_in, a, op == CHOL_BATCH_SYRK ? nullptr : b};
+  rc = tx_follow(X, ins, 3, n);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(dl, hl, 4 * lb, hipMemcpyHostToDevice, s));
   const void *const *d_cin = (const void *const *)dl, *const *d_a = (const void *const *)(dl + lb),
                     *const *d_b = (const void *const *)(dl + 2 * lb);
   void *const *d_out = (void *const *)(dl + 3 * lb);
-  // the private copy of the tile each task updates (W2:212-213), for all tasks in one launch
-  launch_copy_ptrs(s, d_cin, d_out, n, (long)tb);
   for (int t = 0; t < n; ++t) forget_winv(c_out[t]);
-  if (op == CHOL_BATCH_GEMM || op == CHOL_BATCH_SYRK) {
-    launch_gemm_nt_ptrs<T>(s, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, T(-1), T(1),
-                           op == CHOL_BATCH_SYRK);
-  } else {  // TRSM: runs of consecutive tasks with the same L and outputs laid out back to back go out as panels
+  if (update) {
+    // ONE out-of-place launch: c_out = c_in - a b^T (the private copy of W2:212-213 is this write).  The update's waves
+    // yield their CU to the chain's guest kernels when the batch is short against a panel chain (the walker's rule)
+    const int f = dtype == CHOL_REAL_DOUBLE ? 0 : 1;
+    const double t_tile = 2.0 * mb * (double)mb * mb / (g.r.probe_tflops[f] * CHOLMI_UPDATE_EFF * 1e12);
+    const double t_panel = g.r.diag_us[f] * 1e-6 * CHOLMI_STEP_FACTOR * (mb / MACRO);
+    const bool yield = X == TaskExec::BULK && g.r.probe_tflops[f] > 0 && n * t_tile < 3.0 * t_panel;
+    launch_update_ptrs<T>(s, (const T *const *)d_cin, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, yield);
+  } else {
+    // TRSM: private copies, then runs of consecutive tasks with the same L and outputs laid out back to back as panels
+    launch_copy_ptrs(s, d_cin, d_out, n, (long)tb);
     int t0 = 0;
     while (t0 < n) {
       int t1 = t0 + 1;
       while (t1 < n && a[t1] == a[t0] && (const char *)c_out[t1] == (const char *)c_out[t1 - 1] + tb) ++t1;
-      // (at most g_trsm_small_max / nbm tiles per launch: the small-block kernels of the one-tile call, same bits)
-      const int per = std::max(1, cholmi::g_trsm_small_max / (mb / MACRO));
       const T *L = reinterpret_cast<const T *>(a[t0]);
-      // the block inverses the POTRF task of this L left behind (same bits as the one-tile call finds), else recomputed
-      const T *w = reinterpret_cast<const T *>(cached_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype));
+      // the block inverses the POTRF task of this L left behind, else recomputed
+      const T *w = reinterpret_cast<const T *>(tx_cached_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype));
+      // (... or a synchronous chol_potrf_tile on the tagged tile: complete, and not overwritten while this batch runs --
+      // every synchronous call waits for the executor first)
+      if (!w) w = reinterpret_cast<const T *>(cached_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype));
       if (!w) {
-        T *wn = reinterpret_cast<T *>(g.r.winv);
+        T *wn = reinterpret_cast<T *>(tx_winv_set());
         launch_invert_diag<T>(s, L, mb, wn);
-        rc = remember_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype, (size_t)(mb / MACRO) * MACRO * MACRO * sizeof(T));
-        if (rc) return rc;
+        tx_remember_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype, wn);
         w = wn;
       }
-      for (int q = t0; q < t1; q += per)
-        launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[q]), (long)mb * mb, std::min(per, t1 - q), L, w, mb, T(1));
+      launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[t0]), (long)mb * mb, t1 - t0, L, w, mb, T(1));
       t0 = t1;
     }
   }
   HIPCHECK(hipGetLastError());
-  return 0;
+  return tx_commit(X, c_out, n, off, off + 4 * lb);
 }
 
 // POTRF of n HBM-resident tiles, each on its private copy, info per tile in a device slot (read after chol_sync)
 template <typename T>
 static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
                             const unsigned long long *versions, int *slots) {
-  hipStream_t s = g.r.st[ST_MAIN];
+  int rc = tx_init();
+  if (rc) return rc;
+  const int X = TaskExec::CHAIN;
+  hipStream_t s = tx.st[X];
   const size_t tb = (size_t)mb * mb * sizeof(T);
-  if (!g.d_binfo) HIPCHECK(hipMalloc(&g.d_binfo, BINFO_SLOTS * sizeof(int)));
+  if (!g.d_binfo) {
+    HIPCHECK(hipMalloc(&g.d_binfo, BINFO_SLOTS * sizeof(int)));
+    HIPCHECK(hipMemset(g.d_binfo, 0, BINFO_SLOTS * sizeof(int)));
+  }
+  const void *const *ins[1] = {a_in};
+  rc = tx_follow(X, ins, 1, n);
+  if (rc) return rc;
   for (int t = 0; t < n; ++t) {
     const int slot = (int)(g.binfo_next++ % BINFO_SLOTS);
     slots[t] = slot;
     HIPCHECK(hipMemsetAsync(g.d_binfo + slot, 0, sizeof(int), s));
     HIPCHECK(hipMemcpyAsync(a_out[t], a_in[t], tb, hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
-    launch_potrf_tile<T>(s, reinterpret_cast<T *>(a_out[t]), mb, reinterpret_cast<T *>(g.r.winv), g.d_binfo + slot, 0,
-                         tile_sems());
-    int rc = remember_winv(a_out[t], versions ? versions[t] : 0, mb, dtype, (size_t)(mb / MACRO) * MACRO * MACRO * sizeof(T));
-    if (rc) return rc;
-    if (!versions || !versions[t]) forget_winv(a_out[t]);
+    T *wset = reinterpret_cast<T *>(tx_winv_set());
+    launch_potrf_tile<T>(s, reinterpret_cast<T *>(a_out[t]), mb, wset, g.d_binfo + slot, 0, tile_sems());
+    forget_winv(a_out[t]);
+    tx_remember_winv(a_out[t], versions ? versions[t] : 0, mb, dtype, wset);
   }
   HIPCHECK(hipGetLastError());
-  return 0;
+  return tx_commit(X, a_out, n, 0, 0);
 }
 
 extern "C" {
@@ -1048,7 +1234,7 @@ int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *co
   const int rc = dtype == CHOL_REAL_DOUBLE ? potrf_batch_impl<double>(dtype, mb, n, a_in, a_out, versions, slots)
                                            : potrf_batch_impl<float>(dtype, mb, n, a_in, a_out, versions, slots);
   if (rc) return rc;
-  if (!(flags & CHOL_BATCH_ASYNC)) HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  if (!(flags & CHOL_BATCH_ASYNC)) return tx_quiesce();
   return 0;
 }
 
@@ -1056,7 +1242,7 @@ int chol_batch_info(int slot, int *info) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "batch_info before chol_init");
   if (!info || slot < 0 || slot >= BINFO_SLOTS || !g.d_binfo) return fail(-1, "batch_info: slot");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  if (tx.ready) HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));  // (every POTRF batch runs on the chain stream)
   HIPCHECK(hipMemcpy(info, g.d_binfo + slot, sizeof(int), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1064,17 +1250,46 @@ int chol_batch_info(int slot, int *info) {
 int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
                     const void *const *b, void *const *c_out, const unsigned long long *a_versions, int flags) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "tile_batch before chol_init");
-  if (op != CHOL_BATCH_TRSM && op != CHOL_BATCH_SYRK && op != CHOL_BATCH_GEMM) return fail(-1, "tile_batch: op");
+  if (op != CHOL_BATCH_TRSM && op != CHOL_BATCH_SYRK && op != CHOL_BATCH_GEMM && op != CHOL_BATCH_UPDATE) return fail(-1, "tile_batch: op");
   if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-2, "tile_batch: dtype");
   if (mb <= 0 || mb % MACRO || mb > 4096) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_batch: tile edge must be a multiple of 128, at most 4096");
   if (n < 0) return fail(-4, "tile_batch: n");
   if (n == 0) return 0;
-  if (!c_in || !a || !c_out || (op == CHOL_BATCH_GEMM && !b)) return fail(-5, "tile_batch: NULL pointer list");
+  if (!c_in || !a || !c_out || ((op == CHOL_BATCH_GEMM || op == CHOL_BATCH_UPDATE) && !b)) return fail(-5, "tile_batch: NULL pointer list");
+  if (op == CHOL_BATCH_GEMM)
+    for (int t = 0; t < n; ++t)
+      if (!b[t]) return fail(-7, "tile_batch: NULL b operand of a GEMM task");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, dtype, mb, n, c_in, a, b, c_out, a_versions)
-                                           : tile_batch_impl<float>(op, dtype, mb, n, c_in, a, b, c_out, a_versions);
+  const int rc = dtype == CHOL_REAL_DOUBLE ? tile_batch_impl<double>(op, dtype, mb, n, c_in, a, b, c_out, a_versions, flags)
+                                           : tile_batch_impl<float>(op, dtype, mb, n, c_in, a, b, c_out, a_versions, flags);
   if (rc) return rc;
-  if (!(flags & CHOL_BATCH_ASYNC)) HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
+  if (!(flags & CHOL_BATCH_ASYNC)) return tx_quiesce();
+  return 0;
+}
+
+int chol_batch_mark(unsigned long long *mark2) {
+  if (!mark2) return fail(-1, "batch_mark: NULL");
+  mark2[0] = tx.seq[TaskExec::CHAIN], mark2[1] = tx.seq[TaskExec::BULK];
+  return 0;
+}
+
+int chol_batch_wait(const unsigned long long *mark2) {
+  if (!mark2) return fail(-1, "batch_wait: NULL");
+  if (!tx.ready) return 0;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  for (int s = 0; s < 2; ++s) {
+    const unsigned long long want = std::min(mark2[s], tx.seq[s]);
+    if (want == 0 || tx.done[s] >= want) continue;
+    // (an event of the pool that has been recorded again since stands for a LATER batch of the same stream: waiting
+    // for it waits a little longer, never too little)
+    if (int rc = tx_wait_host(s, want)) return rc;
+  }
+  return 0;
+}
+
+int chol_batch_stats(long long *out4) {
+  if (!out4) return fail(-1, "batch_stats: NULL");
+  out4[0] = tx.batches[TaskExec::CHAIN], out4[1] = tx.batches[TaskExec::BULK], out4[2] = tx.cross_waits, out4[3] = (long long)tx.prod.size();
   return 0;
 }
 

@@ -218,10 +218,11 @@ template <typename T>
 void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *B, long sB, int nz2, T *C, long sC1,
                           long sC2, int mb, T alpha, T beta);
 
-// the same product for n (A[z], B[z], C[z]) triples given as device arrays of device pointers, C in place
+// cout[z] = cin[z] - a[z] b[z]^T for n tasks given as device arrays of device tile pointers, out of place; b[z] == null:
+// a SYRK task (b = a, the lower triangle updated, the strict upper one copied) -- kernels.hip: k_update_ptrs_w8
 template <typename T>
-void launch_gemm_nt_ptrs(hipStream_t s, const T *const *A, const T *const *B, T *const *C, int n, int mb, T alpha, T beta,
-                         bool lower_only);
+void launch_update_ptrs(hipStream_t s, const T *const *cin, const T *const *a, const T *const *b, T *const *cout, int n, int mb,
+                        bool yield);
 // dst[z] <- src[z], z < n, `bytes` (a multiple of 16) each; src / dst: device arrays of device pointers
 void launch_copy_ptrs(hipStream_t s, const void *const *src, void *const *dst, int n, long bytes);
 

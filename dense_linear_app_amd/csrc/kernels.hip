@@ -596,6 +596,50 @@ __device__ __forceinline__ void nt_kloop_w8(const T *__restrict__ A, int lda, co
   }
 }
 
+// Cout = Cin - acc for one 128 x 128 block (eight waves, the accumulator layout of nt_kloop_w8): lane (i, q) holds rows
+// 2i, 2i+1 (+32g) of column 32 wc + 2 (q + 4r) + b.  lower: the block lies on the diagonal of a diagonal tile -- only
+// its entries on or below the diagonal are updated (dsyrk Lower, W2:416); OOP (Cout != Cin, the task path's private
+// copy W2:212-213 made by writing elsewhere): the entries above it are copied, in place they are left alone.
+template <typename T, bool OOP>
+__device__ __forceinline__ void w8_epilogue(const T *Cin, T *Cout, int ld,
+                                            typename Tr<T>::acc_t (&acc)[4][2], bool lower) {
+  using vec_t = typename Tr<T>::vec_t;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  const int m0 = wr * 64 + 2 * i;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    vec_t cv[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        cv[r][g] = *reinterpret_cast<const vec_t *>(Cin + (long)(wc * 32 + 2 * (q + 4 * r) + b) * ld + m0 + 32 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 32 + 2 * (q + 4 * r) + b;
+      T *col = Cout + (long)n * ld;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int m = m0 + 32 * g;
+        vec_t v = cv[r][g];
+        if (OOP && lower && m < n) {  // (m even, rows m and m + 1: row m is above the diagonal, row m + 1 maybe not)
+          if (m + 1 >= n) v[1] -= acc[2 * g + 1][b][r];
+          *reinterpret_cast<vec_t *>(col + m) = v;
+          continue;
+        }
+        v[0] -= acc[2 * g][b][r];
+        v[1] -= acc[2 * g + 1][b][r];
+        if (!lower || m >= n) {
+          *reinterpret_cast<vec_t *>(col + m) = v;
+        } else {
+          if (m + 1 >= n) col[m + 1] = v[1];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <typename T, int MODE>
 __device__ __forceinline__ void trail_update_w8_block(const LocalMat &C, const int2 *__restrict__ list, int na, int offb,
                                                       int nb, int blocks_a, const PanelRef &pan, int nbm, int unit,
@@ -621,36 +665,7 @@ __device__ __forceinline__ void trail_update_w8_block(const LocalMat &C, const i
   if (npan > 1)
     nt_kloop_w8<T, MODE>(panel_tile<T>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
                    panel_tile<T>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
-  // C -= acc: lane (i, q) holds rows 2i, 2i+1 (+32g) of column 32 wc + 2 (q + 4r) + b
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
-  const int m0 = wr * 64 + 2 * i;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    vec_t cv[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-        cv[r][g] = *reinterpret_cast<const vec_t *>(Cp + (long)(wc * 32 + 2 * (q + 4 * r) + b) * C.mb + m0 + 32 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = wc * 32 + 2 * (q + 4 * r) + b;
-      T *col = Cp + (long)n * C.mb;
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int m = m0 + 32 * g;
-        vec_t v = cv[r][g];
-        v[0] -= acc[2 * g][b][r];
-        v[1] -= acc[2 * g + 1][b][r];
-        if (!lower || m >= n) {
-          *reinterpret_cast<vec_t *>(col + m) = v;
-        } else {
-          if (m + 1 >= n) col[m + 1] = v[1];
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  w8_epilogue<T, false>(Cp, Cp, C.mb, acc, lower);
 }
 
 template <typename T, int MODE>
@@ -733,6 +748,43 @@ __device__ __forceinline__ void nt_kloop_w8f(const float *__restrict__ A, int ld
   }
 }
 
+// Cout = Cin - acc, fp32 (see w8_epilogue): lane (i, q) holds rows 4i .. 4i+3 of column 32 wc + 2 (4q + r) + b
+template <bool OOP>
+__device__ __forceinline__ void w8f_epilogue(const float *Cin, float *Cout, int ld, f4_t (&acc)[4][2], bool lower) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
+  const int m0 = wr * 64 + 4 * i;
+  f4_t cv[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      cv[b][r] = *reinterpret_cast<const f4_t *>(Cin + (long)(wc * 32 + 2 * (4 * q + r) + b) * ld + m0);
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wc * 32 + 2 * (4 * q + r) + b;
+      float *col = Cout + (long)n * ld;
+      f4_t v = cv[b][r];
+      if (OOP && lower && m0 < n) {  // some of the four rows lie above the diagonal: those are copied
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          if (m0 + a >= n) v[a] -= acc[a][b][r];
+        *reinterpret_cast<f4_t *>(col + m0) = v;
+        continue;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) v[a] -= acc[a][b][r];
+      if (!lower || m0 >= n) {
+        *reinterpret_cast<f4_t *>(col + m0) = v;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          if (m0 + a >= n) col[m0 + a] = v[a];
+      }
+    }
+}
+
 __global__ __launch_bounds__(512, 4) void k_trail_update_w8f(LocalMat C, const int2 *__restrict__ list, int na,
                                                               int offb, int nb, int blocks_a, PanelRef pan, int nbm,
                                                               int unit, const int *ytab, PanelRef pan2, int npan) {
@@ -757,31 +809,91 @@ __global__ __launch_bounds__(512, 4) void k_trail_update_w8f(LocalMat C, const i
   if (npan > 1)
     nt_kloop_w8f(panel_tile<float>(pan2, ij.x, C.bsiz) + mi * MACRO, C.mb,
                  panel_tile<float>(pan2, ij.y, C.bsiz) + mj * MACRO, C.mb, C.mb, acc, sm, yslot);
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w & 1, wc = w >> 1, i = lane & 15, q = lane >> 4;
-  const int m0 = wr * 64 + 4 * i;
-  f4_t cv[2][4];
+  w8f_epilogue<false>(Cp, Cp, C.mb, acc, lower);
+}
+
+// ------------------------------------------------------------------------------
+// The task path's updates (chol_tile_batch: the SYRK / GEMM tasks of a wave, W2:416, 511) on the same eight-wave cores:
+// task t reads its operands through device arrays of tile pointers and writes  cout[t] = cin[t] - a[t] b[t]^T  OUT OF
+// PLACE -- the private copy every task makes of the tile it updates (W2:212-213) is this write, there is no copy pass.
+// b[t] == nullptr marks a SYRK task (b = a, Lower): its blocks above the diagonal copy cin to cout, its diagonal blocks
+// update on or below the diagonal and copy above it.  blockIdx -> (task, block) as in map_update_block's segment A: the
+// MT = nbm^2 blocks of a task and `unit` consecutive blocks of the list stay on one XCD (the operands of consecutive
+// tasks of a wave repeat: same L(i,k) along a row of the trailing matrix).
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ bool map_ptr_block(int n, int nbm, int unit, int &t, int &mi, int &mj) {
+  const int b = blockIdx.x, x = b & 7, sidx = b >> 3, MT = nbm * nbm;
+  const long lin = ((long)(sidx / unit) * 8 + x) * unit + sidx % unit;
+  if (lin >= (long)n * MT) return false;
+  t = (int)(lin / MT);
+  const int macro = (int)(lin - (long)t * MT);
+  mi = macro % nbm;
+  mj = macro / nbm;
+  return true;
+}
+// cout block <- cin block (128 x 128, 512 threads): the blocks of a SYRK task above the diagonal
+template <typename T>
+__device__ __forceinline__ void copy_block_512(const T *cin, T *cout, int ld) {
+  constexpr int EPV = 16 / (int)sizeof(T), VPC = MACRO / EPV;  // 16-byte vectors per column
+  for (int e = threadIdx.x; e < MACRO * VPC; e += 512) {
+    const int c = e / VPC, r = (e % VPC) * EPV;
+    *reinterpret_cast<uint4 *>(cout + r + (long)c * ld) = *reinterpret_cast<const uint4 *>(cin + r + (long)c * ld);
+  }
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 4) void k_update_ptrs_w8(const T *const *__restrict__ cin, const T *const *__restrict__ ap,
+                                                            const T *const *__restrict__ bp, T *const *__restrict__ cout,
+                                                            int n, int mb, int nbm, int unit, const int *ytab) {
+  __shared__ SmemP<T> sm;
+  int t, mi, mj;
+  if (!map_ptr_block(n, nbm, unit, t, mi, mj)) return;
+  const T *A = ap[t], *B = bp[t];
+  const bool syrk = B == nullptr;
+  const long off = mi * MACRO + (long)mj * MACRO * mb;
+  const T *Ci = cin[t] + off;
+  T *Co = cout[t] + off;
+  if (syrk && mi < mj) {
+    copy_block_512<T>(Ci, Co, mb);
+    return;
+  }
+  if (syrk) B = A;
+  typename Tr<T>::acc_t acc[4][2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      cv[b][r] = *reinterpret_cast<const f4_t *>(Cp + (long)(wc * 32 + 2 * (4 * q + r) + b) * C.mb + m0);
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
+  nt_kloop_w8<T, MODE>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm, yslot);
+  w8_epilogue<T, true>(Ci, Co, mb, acc, syrk && mi == mj);
+}
+__global__ __launch_bounds__(512, 4) void k_update_ptrs_w8f(const float *const *__restrict__ cin, const float *const *__restrict__ ap,
+                                                             const float *const *__restrict__ bp, float *const *__restrict__ cout,
+                                                             int n, int mb, int nbm, int unit, const int *ytab) {
+  __shared__ SmemF sm;
+  int t, mi, mj;
+  if (!map_ptr_block(n, nbm, unit, t, mi, mj)) return;
+  const float *A = ap[t], *B = bp[t];
+  const bool syrk = B == nullptr;
+  const long off = mi * MACRO + (long)mj * MACRO * mb;
+  const float *Ci = cin[t] + off;
+  float *Co = cout[t] + off;
+  if (syrk && mi < mj) {
+    copy_block_512<float>(Ci, Co, mb);
+    return;
+  }
+  if (syrk) B = A;
+  f4_t acc[4][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = wc * 32 + 2 * (4 * q + r) + b;
-      float *col = Cp + (long)n * C.mb;
-      f4_t v = cv[b][r];
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) v[a] -= acc[a][b][r];
-      if (!lower || m0 >= n) {
-        *reinterpret_cast<f4_t *>(col + m0) = v;
-      } else {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-          if (m0 + a >= n) col[m0 + a] = v[a];
-      }
-    }
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+  const int *yslot = ytab ? ytab + cu_slot() : nullptr;
+  nt_kloop_w8f(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm, yslot);
+  w8f_epilogue<true>(Ci, Co, mb, acc, syrk && mi == mj);
 }
 
 // X[:, s] := alpha * A[:, s] * Winv_s^T, in place, for row blocks r >= r0 of `ntiles`
@@ -1143,24 +1255,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_tile(const T *__restrict__ A
                  lower && mi == mj);
 }
 
-// The same product for a LIST of tile triples (the tasks of one op class of a wave of the worker path,
-// chol_tile_batch): task z = blockIdx.z reads A[z], B[z] and updates C[z] in place -- the arithmetic of
-// k_gemm_nt_tile, block for block, so a batch gives the bits the one-tile calls give.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_ptrs(const T *const *__restrict__ Ap, const T *const *__restrict__ Bp,
-                                                         T *const *__restrict__ Cp, int mb, int nbm, T alpha, T beta,
-                                                         int lower) {
-  __shared__ SmemP<T> sm;
-  const int mi = blockIdx.x, mj = blockIdx.y;
-  if (lower && mi < mj) return;
-  const T *A = Ap[blockIdx.z], *B = Bp[blockIdx.z];
-  T *C = Cp[blockIdx.z];
-  Acc<T> acc;
-  acc_zero<T>(acc);
-  nt_kloop_paired<T>(A + mi * MACRO, mb, B + mj * MACRO, mb, mb, acc, sm);
-  nt_epilogue_paired<T>(C + mi * MACRO + (long)mj * MACRO * mb, mb, acc, alpha, beta, lower && mi == mj);
-}
-// dst[z] <- src[z], `bytes` (a multiple of 16) each: the private copies the worker makes of the tiles it updates
+// dst[z] <- src[z], `bytes` (a multiple of 16) each: the private copies of the tiles a TRSM batch solves in place
 __global__ __launch_bounds__(256) void k_copy_ptrs(const void *const *__restrict__ src, void *const *__restrict__ dst, long bytes) {
   const uint4 *s = reinterpret_cast<const uint4 *>(src[blockIdx.y]);
   uint4 *d = reinterpret_cast<uint4 *>(dst[blockIdx.y]);
@@ -2755,16 +2850,19 @@ void launch_gemm_nt_batch(hipStream_t s, const T *A, long sA, int nz1, const T *
 }
 
 template <typename T>
-void launch_gemm_nt_ptrs(hipStream_t s, const T *const *A, const T *const *B, T *const *C, int n, int mb, T alpha, T beta,
-                         bool lower_only) {
+void launch_update_ptrs(hipStream_t s, const T *const *cin, const T *const *a, const T *const *b, T *const *cout, int n, int mb,
+                        bool yield) {
+  if (n <= 0) return;
   const int nbm = mb / MACRO;
-  for (int z0 = 0; z0 < n; z0 += 65535) {  // grid.z is a 16-bit quantity
-    const int nz = std::min(65535, n - z0);
-    k_gemm_nt_ptrs<T><<<dim3(nbm, nbm, nz), 256, 0, s>>>(A + z0, B + z0, C + z0, mb, nbm, alpha, beta, lower_only ? 1 : 0);
-  }
+  const UpdateGrid u = update_grid((long)n * nbm * nbm, 0, false);
+  const dim3 grid((unsigned)u.blocks_a);
+  if constexpr (sizeof(T) == 4)
+    k_update_ptrs_w8f<<<grid, dim3(512), 0, s>>>(cin, a, b, cout, n, mb, nbm, u.unit, yield ? g_ytab : nullptr);
+  else
+    k_update_ptrs_w8<T, 3><<<grid, dim3(512), 0, s>>>(cin, a, b, cout, n, mb, nbm, u.unit, yield ? g_ytab : nullptr);
 }
-template void launch_gemm_nt_ptrs<double>(hipStream_t, const double *const *, const double *const *, double *const *, int, int, double, double, bool);
-template void launch_gemm_nt_ptrs<float>(hipStream_t, const float *const *, const float *const *, float *const *, int, int, float, float, bool);
+template void launch_update_ptrs<double>(hipStream_t, const double *const *, const double *const *, const double *const *, double *const *, int, int, bool);
+template void launch_update_ptrs<float>(hipStream_t, const float *const *, const float *const *, const float *const *, float *const *, int, int, bool);
 
 void launch_copy_ptrs(hipStream_t s, const void *const *src, void *const *dst, int n, long bytes) {
   for (int z0 = 0; z0 < n; z0 += 65535) {

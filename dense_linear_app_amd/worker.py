@@ -160,12 +160,14 @@ class HipTileBackend:
         res = torch.empty(m * B * B, dtype=torch.float64, device="cuda")
         return res, res.data_ptr()
 
-    def tile_batch(self, code: int, B: int, m: int, ptr) -> int:
+    def tile_batch(self, code: int, B: int, m: int, ptr, urgent: bool = False) -> int:
+        """code: 1 TRSM, 4 UPDATE (the SYRK and GEMM tasks of a wave in ONE out-of-place launch; ptr[2] == 0 marks a SYRK
+        task).  urgent: the tasks feed the panel chain (column k+1) -- the library runs them on its chain stream."""
         from ._lib import lib
 
         return lib().chol_tile_batch(code, ch.ChamRealDouble, B, m, ptr[0].ctypes.data, ptr[1].ctypes.data,
-                                     ptr[2].ctypes.data if code == 3 else None, ptr[3].ctypes.data,
-                                     ptr[4].ctypes.data if code == 1 else None, 1)
+                                     ptr[2].ctypes.data if code == 4 else None, ptr[3].ctypes.data,
+                                     ptr[4].ctypes.data if code == 1 else None, 3 if urgent else 1)
 
     def potrf_batch(self, B: int, m: int, ptr, slots) -> int:
         from ._lib import lib
@@ -380,13 +382,16 @@ class DagCholeskyWorker(ArmoniKWorker):
 
 
     # ---------------------------------------------------------------- a whole op class of a wave at once
-    _BATCH_OP = {"TRSM": 1, "SYRK": 2, "GEMM": 3}  # include/cholmi.h: CHOL_BATCH_*
+    _BATCH_OP = {"TRSM": 1, "SYRK": 2, "GEMM": 3}  # chol_parse_payloads' op codes (POTRF: 4)
 
     def ExecuteBatch(self, handlers) -> list:  # noqa: N802, C901
         """every ready task of a wave handed over together.  Same payloads, same checks and the same
-        ProcessStatus per task as Execute; the TRSM / SYRK / GEMM tasks whose tiles are HBM-resident (DeviceBlob)
-        are issued as ONE grouped launch per op class (chol_tile_batch: bit-identical to the one-tile calls),
-        asynchronously -- their results are device blobs ordered on the library's stream.  Everything else
+        ProcessStatus per task as Execute; the tasks whose tiles are HBM-resident (DeviceBlob) are issued as grouped
+        launches (chol_tile_batch: the TRSM tasks one, the SYRK and GEMM tasks together ONE out-of-place launch),
+        asynchronously -- their results are device blobs ordered by the library's dependency-driven executor (a batch
+        waits for exactly the batches that write what it reads).  Tasks submitted with a TaskOptions.priority above
+        the default (C2:335) are the panel chain's: their launches go to the library's chain stream, ahead of the
+        bulk of the wave's update.  Everything else
         (POTRF unless async_potrf, host blobs, any task that fails a check) goes through Execute.
         The payloads of the batch are read by ONE call of the library's flat reader (chol_parse_payloads: W2:47-69,
         batched); a payload it does not take goes to handle_json, whose verdict is then reported."""
@@ -429,9 +434,11 @@ class DagCholeskyWorker(ArmoniKWorker):
                 if not ok:
                     out[idx] = self._execute_one(h)  # (missing / short / host blobs: the one-task path reports them)
                     continue
-                g = groups.get((code, B))
+                # launch class: 1 TRSM, 2 the updates (SYRK and GEMM together), 4 POTRF; the chain's tasks apart
+                key = (code if code != 3 else 2, B, h.priority() > 1)
+                g = groups.get(key)
                 if g is None:
-                    g = groups[(code, B)] = ([], [], [], [], [])  # task index, three operand pointers, tag
+                    g = groups[key] = ([], [], [], [], [])  # task index, three operand pointers, tag
                 g[0].append(idx)
                 g[1].append(b0.ptr)
                 g[2].append(b1.ptr if b1 is not None else 0)
@@ -442,7 +449,7 @@ class DagCholeskyWorker(ArmoniKWorker):
         if groups:
             be.sync_inputs()  # uploads made through torch are visible to the library's stream
         ok_status = ProcessStatus.Ok
-        for (code, B), (idxs, p0, p1, p2, tags) in groups.items():
+        for (code, B, urgent), (idxs, p0, p1, p2, tags) in sorted(groups.items(), key=lambda kv: not kv[0][2]):  # the chain's first
             m = len(idxs)
             tb = B * B * 8
             res, base = be.batch_alloc(m, B)
@@ -460,13 +467,18 @@ class DagCholeskyWorker(ArmoniKWorker):
             else:
                 if code == 1:  # panels: the tasks that share an L side by side
                     order = np.argsort(ptr[1], kind="stable")
-                    ptr[:3] = ptr[:3, order]
-                    ptr[4] = ptr[4, order]
-                    idxs = [idxs[int(o)] for o in order]
+                    nsyrk = 0
+                else:  # the SYRK tasks (no second operand) last: their blocks above the diagonal only copy, and a tile
+                    # whose workgroups leave early in the middle of a launch costs the L2 its operand reuse
+                    order = np.argsort(ptr[2] == 0, kind="stable")
+                    nsyrk = int(np.count_nonzero(ptr[2] == 0))
+                ptr[:3] = ptr[:3, order]
+                ptr[4] = ptr[4, order]
+                idxs = [idxs[int(o)] for o in order]
                 t0 = time.perf_counter()
-                rc = be.tile_batch(code, B, m, ptr)
-                opname = ("", "TRSM", "SYRK", "GEMM")[code]
-                flops = (1.0, 1.0, 1.0, 2.0)[code] * m * B * B * B
+                rc = be.tile_batch(1 if code == 1 else 4, B, m, ptr, urgent)
+                opname = "TRSM" if code == 1 else ("SYRK" if nsyrk == m else "GEMM")
+                flops = (1.0 * m if code == 1 else 2.0 * m - nsyrk) * B * B * B
             self.batches += 1
             self.batched_tasks += m
             DeviceBlob.pending_epoch += 1
@@ -488,6 +500,22 @@ class DagCholeskyWorker(ArmoniKWorker):
                 except Exception as e:
                     out[i] = ProcessStatus(("[Worker][POTF] " if code == 4 else "") + "send_result failed: " + str(e))
         return out
+
+    def mark(self):
+        """Everything ExecuteBatch has enqueued so far (chol_batch_mark): wait_mark(m) blocks until that much has run,
+        without draining what was enqueued after it."""
+        import ctypes as C
+
+        from ._lib import lib
+
+        m = (C.c_ulonglong * 2)()
+        lib().chol_batch_mark(m)
+        return m
+
+    def wait_mark(self, m) -> None:
+        from ._lib import lib
+
+        lib().chol_batch_wait(m)
 
     def sync(self) -> bool:
         """Wait for everything ExecuteBatch enqueued; -> False if an asynchronously factored tile has failed (flush()

@@ -132,20 +132,30 @@ int chol_gemm_tile(int transA, int transB, double alpha, chol_desc_t *A, chol_de
 
 /* The tasks of ONE op class of a wave in one grouped launch ("submit a whole wave, one wait per
  * wave"; W2:323 / 416 / 511 executed for n tasks at once), on HBM-resident mb x mb tiles (mb a multiple of 128):
- *   CHOL_BATCH_TRSM  c_out[t] = c_in[t] * a[t]^{-T}           (Right, Lower, Trans, NonUnit; a[t] = L(k,k))
- *   CHOL_BATCH_SYRK  c_out[t] = c_in[t] - a[t] a[t]^T, lower triangle (the strict upper triangle is copied)
- *   CHOL_BATCH_GEMM  c_out[t] = c_in[t] - a[t] b[t]^T
- * c_in / a / b / c_out: HOST arrays of n device pointers (b ignored unless GEMM).  Every task first takes its
- * private copy c_out[t] <- c_in[t] (W2:212-213), then the same kernels as the one-tile calls update it: results
- * are bit-identical to n calls of chol_trsm_tile / chol_syrk_tile / chol_gemm_tile on device buffers.
+ *   CHOL_BATCH_TRSM    c_out[t] = c_in[t] * a[t]^{-T}           (Right, Lower, Trans, NonUnit; a[t] = L(k,k))
+ *   CHOL_BATCH_SYRK    c_out[t] = c_in[t] - a[t] a[t]^T, lower triangle (the strict upper triangle is copied)
+ *   CHOL_BATCH_GEMM    c_out[t] = c_in[t] - a[t] b[t]^T
+ *   CHOL_BATCH_UPDATE  the SYRK and GEMM tasks of a wave together: b[t] == NULL marks a SYRK task
+ * c_in / a / b / c_out: HOST arrays of n device pointers (b ignored for TRSM / SYRK).  c_out[t] must not alias an
+ * input: every task writes its private copy (W2:212-213) -- SYRK / GEMM / UPDATE in ONE out-of-place launch of the
+ * trailing-update kernel (the copy IS the kernel's write: no copy pass), TRSM after a copy launch.  Results agree
+ * with n calls of chol_trsm_tile / chol_syrk_tile / chol_gemm_tile to rounding (same products, same K order; the
+ * kernels differ, so bit-identity is not promised).
  * a_versions (may be NULL): content tags of the a[t] buffers (chol_desc_set_version's meaning) -- TRSM reuses
- * the block inverses kept for (a[t], tag) by the POTRF task instead of re-inverting L(k,k).
- * flags: CHOL_BATCH_ASYNC -- return once the work is enqueued on the library's stream (later library calls are
- * ordered behind it; chol_sync() waits for it). */
-enum { CHOL_BATCH_TRSM = 1, CHOL_BATCH_SYRK = 2, CHOL_BATCH_GEMM = 3 };
-enum { CHOL_BATCH_ASYNC = 1 };
+ * the block inverses kept for (a[t], tag) by the POTRF batch instead of re-inverting L(k,k).
+ * flags: CHOL_BATCH_ASYNC -- return once the work is enqueued (later batches are ordered behind it by what they
+ *        read: see below; chol_sync() waits for everything).
+ *        CHOL_BATCH_URGENT -- (SYRK / GEMM / UPDATE) the tasks feed the panel chain: column k+1 of wave k.
+ * Execution is dependency-driven on two streams: POTRF and TRSM batches and URGENT updates run on a high-priority
+ * chain stream, other updates on the bulk stream; a batch that reads a tile written by a batch of the other stream
+ * waits for exactly that batch (tile pointers are the keys: results are write-once buffers).  So POTRF / TRSM of
+ * wave k+1 run beside the bulk update of wave k, as in the whole-matrix walker, whenever the caller submits column
+ * k+1's tasks URGENT and ahead of the rest (the reference's TaskOptions.priority, C2:335, is the natural carrier). */
+enum { CHOL_BATCH_TRSM = 1, CHOL_BATCH_SYRK = 2, CHOL_BATCH_GEMM = 3, CHOL_BATCH_UPDATE = 4 };
+enum { CHOL_BATCH_ASYNC = 1, CHOL_BATCH_URGENT = 2 };
 int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
                     const void *const *b, void *const *c_out, const unsigned long long *a_versions, int flags);
+/* Waits for everything enqueued by the batch calls (both streams) and for the library's main stream. */
 int chol_sync(void);
 /* The POTRF tasks of a wave the same way: a_out[t] <- a_in[t] (private copy), factored Lower in place.  versions
  * (may be NULL) tags a_out[t]'s content, so that its block inverses serve the TRSM batch that follows.  The
@@ -155,6 +165,14 @@ int chol_sync(void);
 int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
                      const unsigned long long *versions, int *slots, int flags);
 int chol_batch_info(int slot, int *info);
+/* A mark = the batches enqueued so far (mark2: two sequence numbers, chain and bulk stream); chol_batch_wait blocks
+ * until everything up to a mark has run WITHOUT draining what was enqueued after it -- what a client that releases
+ * superseded tile versions needs: the readers of a version were all enqueued before the mark taken after them. */
+int chol_batch_mark(unsigned long long *mark2);
+int chol_batch_wait(const unsigned long long *mark2);
+/* Executor statistics since chol_init: out4 = {batches on the chain stream, batches on the bulk stream, event waits
+ * between the two, tile pointers currently remembered} (bench.py / tests: the overlap is really there). */
+int chol_batch_stats(long long *out4);
 
 /* CHAMELEON_dplgsy_Tile(bump, uplo, A, seed) V6:46: Chameleon's generator (published
  * core_dplgsy: 64-bit LCG with jump-ahead, entry (i,j), i >= j, = 0.5 - ran_{i + j*m} / 2^64,

@@ -22,7 +22,7 @@ class NullBatchBackend(HipTileBackend):
     def batch_alloc(self, m, B):
         NullBatchBackend.next_ptr += m * B * B * 8
         return _Fake(m * B * B * 8, NullBatchBackend.next_ptr), NullBatchBackend.next_ptr
-    def tile_batch(self, code, B, m, ptr): return 0
+    def tile_batch(self, code, B, m, ptr, urgent=False): return 0
     def potrf_batch(self, B, m, ptr, slots): return 0
 
 

@@ -414,6 +414,19 @@ def test_tile_batches_through_the_raw_abi(cham, dtype):
                 ref = Cq - Aq @ Bq.T
             assert np.abs(got - ref).max() <= tol * B * max(1.0, np.abs(ref).max()), (code, q)
             assert np.array_equal(host(dC[q]), Cq)
+    # CHOL_BATCH_UPDATE: SYRK and GEMM tasks in ONE launch (b == NULL marks the SYRK task), out of place
+    out.zero_()
+    mixed = (C.c_void_p * n)(dB[0].data_ptr(), None, dB[2].data_ptr())
+    assert L.chol_tile_batch(4, cdt, B, n, ptrs(dC), ptrs(dA), mixed, ptrs(outs), None, 0) == 0, L.chol_last_error()
+    for q in range(n):
+        Cq, Aq, Bq = Cs[q].astype(np.float64), As[q].astype(np.float64), Bs[q].astype(np.float64)
+        ref = Cq - Aq @ (Aq if q == 1 else Bq).T
+        if q == 1:
+            ref[np.triu_indices(B, 1)] = Cq[np.triu_indices(B, 1)]
+        assert np.abs(host(outs[q]) - ref).max() <= tol * B * max(1.0, np.abs(ref).max()), q
+        if q == 1:
+            assert np.array_equal(np.triu(host(outs[q]), 1), np.triu(Cq, 1))  # copied bit for bit
+    assert L.chol_tile_batch(3, cdt, B, n, ptrs(dC), ptrs(dA), mixed, ptrs(outs), None, 0) < 0  # a GEMM task needs its b
     assert L.chol_tile_batch(9, cdt, B, n, ptrs(dC), ptrs(dA), None, ptrs(outs), None, 0) < 0
     assert L.chol_tile_batch(3, cdt, 100, n, ptrs(dC), ptrs(dA), ptrs(dB), ptrs(outs), None, 0) == -104
 
@@ -495,3 +508,57 @@ def test_sub_matrix_view_with_unaligned_offsets(cham, orc, where):
     # a user matrix that is not made of whole tiles stays refused
     with pytest.raises(ch.CholmiError, match="whole square tiles"):
         ch.CHAMELEON_Desc_Create(buf, ch.ChamRealDouble, mb, mb, mb * mb, lm - 10, lm - 10, 100, 0, m, m, 1, 1)
+
+
+def test_batches_on_the_two_streams_are_ordered_by_what_they_read(cham):
+    """The executor behind chol_tile_batch (api.hip: TaskExec): URGENT updates, TRSM and POTRF batches run on the chain
+    stream, other updates on the bulk stream, and a batch that reads a tile written on the other stream waits for exactly
+    that batch.  A ladder of asynchronous batches that alternates between the streams, each consuming the tile the one
+    before produced (long bulk batches ahead of short urgent ones, so that a missing wait would read a tile not yet
+    written), against numpy; the statistics say that both streams were used and that events ordered them."""
+    import torch
+
+    from dense_linear_app_amd._lib import lib
+
+    ch, L = cham, lib()
+    B, steps, fill = 512, 6, 24
+    rng = np.random.default_rng(11)
+
+    def dev(a):
+        return torch.from_numpy(np.asfortranarray(a).ravel(order="F").copy()).cuda()
+
+    def host(t):
+        return t.cpu().numpy().reshape((B, B), order="F")
+
+    def ptrs(ts):
+        return (C.c_void_p * len(ts))(*[int(t.data_ptr()) if t is not None else None for t in ts])
+
+    C0 = rng.standard_normal((B, B))
+    As = [rng.standard_normal((B, B)) / 8 for _ in range(steps)]
+    Bs = [rng.standard_normal((B, B)) / 8 for _ in range(steps)]
+    dA, dB = [dev(a) for a in As], [dev(b) for b in Bs]
+    filler_c = [dev(rng.standard_normal((B, B))) for _ in range(fill)]
+    torch.cuda.synchronize()
+    st0 = (C.c_longlong * 4)()
+    assert L.chol_batch_stats(st0) == 0
+    cur, ref = dev(C0), C0.copy()
+    keep = [cur]
+    for s in range(steps):
+        urgent = s % 2 == 1
+        # the link of the ladder first in a bulk batch, behind it `fill` independent tasks: the next (urgent) batch must wait for all of it
+        n = 1 if urgent else 1 + fill
+        outs = [torch.empty(B * B, dtype=torch.float64, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        cin = [cur] + ([] if urgent else filler_c)
+        rc = L.chol_tile_batch(4, ch.ChamRealDouble, B, n, ptrs(cin), ptrs([dA[s]] * n), ptrs([dB[s]] * n), ptrs(outs), None, 3 if urgent else 1)
+        assert rc == 0, L.chol_last_error()
+        ref = ref - As[s] @ Bs[s].T
+        cur = outs[0]
+        keep.append(outs)
+    assert L.chol_sync() == 0
+    assert np.abs(host(cur) - ref).max() <= 1e-12 * B * np.abs(ref).max()
+    st1 = (C.c_longlong * 4)()
+    assert L.chol_batch_stats(st1) == 0
+    chain, bulk, waits = st1[0] - st0[0], st1[1] - st0[1], st1[2] - st0[2]
+    assert chain == steps // 2 and bulk == steps - steps // 2 and waits >= steps - 2, (chain, bulk, waits)
+    assert st1[3] == 0  # chol_sync forgot every tile

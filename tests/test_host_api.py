@@ -245,9 +245,10 @@ def test_c_driver_builds_as_c99_and_fails_loudly_without_a_gpu():
         assert r.returncode == 2 and "no HIP device" in r.stderr
 
 
-def test_batched_client_is_the_same_dag_with_three_submissions_per_wave():
-    """the non-blocking client.  Same tasks, payloads and results; 3 submit_tasks
-    calls per wave instead of one per task."""
+def test_batched_client_is_the_same_dag_with_four_submissions_per_wave():
+    """the non-blocking client.  Same tasks, payloads and results; 4 submit_tasks calls per wave (POTRF; the
+    TRSMs; the updates of column k+1, i.e. the panel chain's, with TaskOptions.priority 2; the other updates) instead of
+    one per task."""
     import sys
 
     sys.path.insert(0, os.path.dirname(__file__))
@@ -274,7 +275,7 @@ def test_batched_client_is_the_same_dag_with_three_submissions_per_wave():
     finally:
         ak.TasksClient.submit_tasks = orig
     assert serial.task_counts == batched.task_counts == {"POTRF": 6, "TRSM": 15, "SYRK": 15, "GEMM": 20}
-    assert n_serial == 56 and n_batched == 3 * 6 - 2  # the last wave has no TRSM and no updates
+    assert n_serial == 56 and n_batched == 4 * 6 - 4  # the last wave is a POTRF alone, the one before has no update beyond column k+1
     assert np.array_equal(serial.lower_factor(), batched.lower_factor())
 
 
