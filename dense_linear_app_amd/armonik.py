@@ -35,14 +35,29 @@ from dataclasses import dataclass, field
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 
+# The per-task loops of this module and of worker.ExecuteBatch exist twice: in Python (below) and in C
+# (csrc/fastplane.c, on the same objects).  FAST = None forces the Python ones (tests compare the two; a build
+# without the extension works, 3-4 us per task slower).
+try:
+    from . import _fastplane as FAST
+except ImportError:  # pragma: no cover - the extension is built by `make -C dense_linear_app_amd/csrc`
+    FAST = None
+
 _ID_PREFIX = uuid.uuid4().hex[:12]
-_ID_COUNTER = itertools.count(1)
+_ID_NEXT = [1]
+
+
+def _reserve_ids(n: int) -> int:
+    """-> the first of n consecutive id numbers"""
+    start = _ID_NEXT[0]
+    _ID_NEXT[0] = start + n
+    return start
 
 
 def _new_id() -> str:
     """An opaque unique id (the ArmoniK server hands out uuids; here: a per-process random prefix and a counter,
     a tenth of the cost of uuid4 -- it is paid three times per task)."""
-    return f"{_ID_PREFIX}-{next(_ID_COUNTER):08x}"
+    return f"{_ID_PREFIX}-{_reserve_ids(1):08x}"
 
 
 # ------------------------------------------------------------------------------ value types
@@ -268,12 +283,17 @@ class ControlPlane:
         self._tasks: Dict[str, _Task] = {}
         self._pending: List[str] = []
         self._workers: Dict[str, ArmoniKWorker] = {}
+        self._batch_parts: set = set()  # partitions whose worker takes a whole batch (ExecuteBatch)
         self.executed: List[str] = []  # task ids in execution order
         self.on_task_done: Optional[Callable[[_Task], None]] = None
 
     # -- deployment
     def register_worker(self, partition_id: str, worker: ArmoniKWorker) -> None:
         self._workers[partition_id] = worker
+        if hasattr(worker, "ExecuteBatch"):
+            self._batch_parts.add(partition_id)
+        else:
+            self._batch_parts.discard(partition_id)
 
     # -- internals
     def _complete_result(self, result_id: str, data) -> None:
@@ -330,7 +350,10 @@ class ControlPlane:
         worker answers with one ProcessStatus per task; bookkeeping per task is that of _run."""
         worker = self._workers.get(tasks[0].options.partition_id)
         try:
-            statuses = worker.ExecuteBatch([TaskHandler(self, t.session_id, t) for t in tasks])
+            if FAST is not None and hasattr(worker, "ExecuteTasks"):
+                statuses = worker.ExecuteTasks(self, tasks)  # (handlers are made for the tasks that need one only)
+            else:
+                statuses = worker.ExecuteBatch([TaskHandler(self, t.session_id, t) for t in tasks])
             if len(statuses) != len(tasks):
                 raise RuntimeError("ExecuteBatch returned a status list of the wrong length")
         except Exception:  # a crashing batch: fall back to the one-task path with its retry rule
@@ -358,6 +381,10 @@ class ControlPlane:
                         self.on_task_done(t)
             return
         res, ok_status, executed, done_cb = self._results, ProcessStatus.Ok, self.executed, self.on_task_done
+        if FAST is not None and done_cb is None and isinstance(statuses, list):
+            # the common case (Ok, the one result there) booked in C; the rest below
+            slow = FAST.book_batch(tasks, statuses, res, executed, ok_status)
+            tasks, statuses = [tasks[i] for i in slow], [statuses[i] for i in slow]
         for t, status in zip(tasks, statuses):
             t.attempts += 1
             t.output = status
@@ -423,12 +450,15 @@ class ControlPlane:
                 by_part: Dict[str, List[_Task]] = {}
                 rest = []
                 tasks, ready_fn, workers = self._tasks, self._ready, self._workers
-                for tid in self._pending:  # one pass: the ready tasks of partitions with a batch-capable worker leave the list
-                    t = tasks[tid]
-                    if ready_fn(t) and hasattr(workers.get(t.options.partition_id), "ExecuteBatch"):
-                        by_part.setdefault(t.options.partition_id, []).append(t)
-                    else:
-                        rest.append(tid)
+                if FAST is not None:
+                    by_part, rest = FAST.split_ready(self._pending, tasks, self._results, self._batch_parts)
+                else:
+                    for tid in self._pending:  # one pass: the ready tasks of partitions with a batch-capable worker leave the list
+                        t = tasks[tid]
+                        if ready_fn(t) and hasattr(workers.get(t.options.partition_id), "ExecuteBatch"):
+                            by_part.setdefault(t.options.partition_id, []).append(t)
+                        else:
+                            rest.append(tid)
                 if by_part:
                     self._pending = rest
                     for ts in by_part.values():
@@ -468,6 +498,9 @@ class ResultsClient:
         """name -> fresh result id (C2:373, 471).  Results are write-once."""
         if session_id not in self._plane._sessions:
             raise KeyError(f"unknown session {session_id}")
+        if FAST is not None:
+            names = names if isinstance(names, (list, tuple)) else list(names)
+            return FAST.create_results(self._plane._results, _Result, _ID_PREFIX, _reserve_ids(len(names)), names, session_id)
         out = {}
         for n in names:
             rid = _new_id()
@@ -488,6 +521,13 @@ class ResultsClient:
         """upload_result_data for several results in one call (one gRPC stream in the SDK's bulk uploads): the tasks
         they complete the inputs of are looked at once, at the end."""
         plane = self._plane
+        if FAST is not None:
+            ids = list(items)
+            datas = [v.encode("utf-8") if isinstance(v, str) else v for v in items.values()]
+            # (payloads -- host bytes by rule -- in one go; anything else falls through to the general loop untouched)
+            if FAST.complete_many(plane._results, ids, datas, "payload" if plane.device_results else None):
+                plane._pump()
+                return
         for result_id, data in items.items():
             if isinstance(data, str):
                 data = data.encode("utf-8")
@@ -525,6 +565,10 @@ class TasksClient:
         shared = opts.copy()  # (one private copy per submission: the tasks of a call share their options)
         ids = []
         results, tasks, pending = self._plane._results, self._plane._tasks, self._plane._pending
+        if FAST is not None:
+            ids = FAST.submit(tasks, pending, results, task_creations, _Task, _ID_PREFIX, _reserve_ids(len(task_creations)), session_id, shared)
+            self._plane._pump()
+            return ids
         for tc in task_creations:
             if tc.payload_id not in results:
                 raise KeyError(f"submit_tasks: unknown result id {tc.payload_id}")

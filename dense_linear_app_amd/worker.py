@@ -29,7 +29,7 @@ from typing import Optional
 import numpy as np
 
 from . import chameleon as ch
-from .armonik import ArmoniKWorker, DeviceBlob, ProcessStatus, TaskHandler
+from .armonik import ArmoniKWorker, DeviceBlob, ProcessStatus, TaskHandler  # noqa: F401
 
 
 @dataclass
@@ -146,7 +146,19 @@ class HipTileBackend:
         rc = lib().chol_parse_payloads(buf, off.ctypes.data, n, op.ctypes.data, Bs.ctypes.data, io.ctypes.data, il.ctypes.data)
         if rc != 0:
             raise RuntimeError("chol_parse_payloads failed")
-        return buf, op.tolist(), Bs.tolist(), io.tolist(), il.tolist()
+        return buf, op, Bs, io, il
+
+    def parse_joined(self, buf: bytes, off: bytes, n: int):
+        """parse_payloads on payloads that are already back to back (armonik.FAST.payload_join): arrays, not lists."""
+        from ._lib import lib
+
+        op, Bs = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        io, il = np.empty(3 * n, dtype=np.int64), np.empty(3 * n, dtype=np.int32)
+        offs = np.frombuffer(off, dtype=np.int64)
+        rc = lib().chol_parse_payloads(buf, offs.ctypes.data, n, op.ctypes.data, Bs.ctypes.data, io.ctypes.data, il.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("chol_parse_payloads failed")
+        return buf, op, Bs, io, il
 
     def sync_inputs(self) -> None:
         import torch
@@ -395,59 +407,88 @@ class DagCholeskyWorker(ArmoniKWorker):
         (POTRF unless async_potrf, host blobs, any task that fails a check) goes through Execute.
         The payloads of the batch are read by ONE call of the library's flat reader (chol_parse_payloads: W2:47-69,
         batched); a payload it does not take goes to handle_json, whose verdict is then reported."""
+        if not handlers:
+            return []
+        return self.ExecuteTasks(handlers[0]._plane, [h._task for h in handlers], handlers)
+
+    def ExecuteTasks(self, plane, tasks, handlers=None) -> list:  # noqa: N802, C901
+        """ExecuteBatch on the control plane's task records (a TaskHandler is made only for a task that takes the one-task
+        path).  The two per-task loops -- resolving the payloads' tile ids to HBM addresses, and sending the results --
+        run in C when the extension is there (armonik.FAST: csrc/fastplane.c, same objects, same checks)."""
         import ctypes as C
 
-        n = len(handlers)
+        from . import armonik as ak
+
+        n = len(tasks)
         out: list = [None] * n
         be = self.backend
+
+        def handler(i):
+            if handlers is not None:
+                return handlers[i]
+            t = tasks[i]
+            return TaskHandler(plane, t.session_id, t)
+
         if not isinstance(be, HipTileBackend):
-            return [self._execute_one(h) for h in handlers]
+            return [self._execute_one(handler(i)) for i in range(n)]
+        fast = ak.FAST
+        results = plane._results
         try:
-            payloads = [h.payload_bytes() for h in handlers]
-            buf, ops, Bs, id_off, id_len = be.parse_payloads(payloads)
+            joined = fast.payload_join(tasks, results) if fast is not None else None
+            if joined is not None:
+                buf, ops, Bs, id_off, id_len = be.parse_joined(joined[0], joined[1], n)
+            else:
+                payloads = [handler(i).payload_bytes() for i in range(n)]
+                buf, ops, Bs, id_off, id_len = be.parse_payloads(payloads)
         except Exception:  # (a payload that is not even bytes: the one-task path reports it)
-            return [self._execute_one(h) for h in handlers]
-        groups: dict = {}
+            return [self._execute_one(handler(i)) for i in range(n)]
         async_potrf = self.async_potrf
-        for idx in range(n):
-            code, B = ops[idx], Bs[idx]
-            h = handlers[idx]
-            if code <= 0 or B <= 0 or B % 128 or (code == 4 and not async_potrf):
-                out[idx] = self._execute_one(h)  # (other ops, odd tile sizes, unreadable payloads: Execute's own messages)
-                continue
-            try:
-                o = 3 * idx
-                want = B * B * 8
-                b0 = h.dependency(buf[id_off[o]:id_off[o] + id_len[o]].decode())
-                ok = isinstance(b0, DeviceBlob) and b0.nbytes == want
-                tag = 0
-                b1 = b2 = None
-                if ok and code != 4:
-                    id1 = buf[id_off[o + 1]:id_off[o + 1] + id_len[o + 1]].decode()
-                    b1 = h.dependency(id1)
-                    ok = isinstance(b1, DeviceBlob) and b1.nbytes == want
-                    if ok and code == 1:
-                        tag = _tag_of(id1)
-                    elif ok and code == 3:
-                        b2 = h.dependency(buf[id_off[o + 2]:id_off[o + 2] + id_len[o + 2]].decode())
-                        ok = isinstance(b2, DeviceBlob) and b2.nbytes == want
-                if not ok:
-                    out[idx] = self._execute_one(h)  # (missing / short / host blobs: the one-task path reports them)
+        if fast is not None:
+            groups, fallback = fast.resolve_batch(tasks, results, buf, ops, Bs, id_off, id_len, DeviceBlob, bool(async_potrf))
+            for idx in fallback:
+                out[idx] = self._execute_one(handler(idx))  # (other ops, odd tile sizes, missing / short / host blobs: Execute's own messages)
+        else:
+            groups = {}
+            ops, Bs, id_off, id_len = ops.tolist(), Bs.tolist(), id_off.tolist(), id_len.tolist()
+            for idx in range(n):
+                code, B = ops[idx], Bs[idx]
+                if code <= 0 or B <= 0 or B % 128 or (code == 4 and not async_potrf):
+                    out[idx] = self._execute_one(handler(idx))  # (other ops, odd tile sizes, unreadable payloads: Execute's own messages)
                     continue
-                # launch class: 1 TRSM, 2 the updates (SYRK and GEMM together), 4 POTRF; the chain's tasks apart
-                key = (code if code != 3 else 2, B, h.priority() > 1)
-                g = groups.get(key)
-                if g is None:
-                    g = groups[key] = ([], [], [], [], [])  # task index, three operand pointers, tag
-                g[0].append(idx)
-                g[1].append(b0.ptr)
-                g[2].append(b1.ptr if b1 is not None else 0)
-                g[3].append(b2.ptr if b2 is not None else 0)
-                g[4].append(tag)
-            except Exception as e:  # W2:558-560
-                out[idx] = ProcessStatus("Exception: " + str(e))
+                try:
+                    h = handler(idx)
+                    o = 3 * idx
+                    want = B * B * 8
+                    b0 = h.dependency(buf[id_off[o]:id_off[o] + id_len[o]].decode())
+                    ok = isinstance(b0, DeviceBlob) and b0.nbytes == want
+                    tag = 0
+                    b1 = b2 = None
+                    if ok and code != 4:
+                        id1 = buf[id_off[o + 1]:id_off[o + 1] + id_len[o + 1]].decode()
+                        b1 = h.dependency(id1)
+                        ok = isinstance(b1, DeviceBlob) and b1.nbytes == want
+                        if ok and code == 1:
+                            tag = _tag_of(id1)
+                        elif ok and code == 3:
+                            b2 = h.dependency(buf[id_off[o + 2]:id_off[o + 2] + id_len[o + 2]].decode())
+                            ok = isinstance(b2, DeviceBlob) and b2.nbytes == want
+                    if not ok:
+                        out[idx] = self._execute_one(h)  # (missing / short / host blobs: the one-task path reports them)
+                        continue
+                    # launch class: 1 TRSM, 2 the updates (SYRK and GEMM together), 4 POTRF; the chain's tasks apart
+                    key = (code if code != 3 else 2, B, h.priority() > 1)
+                    g = groups.get(key)
+                    if g is None:
+                        g = groups[key] = ([], [], [], [], [])  # task index, three operand pointers, tag
+                    g[0].append(idx)
+                    g[1].append(b0.ptr)
+                    g[2].append(b1.ptr if b1 is not None else 0)
+                    g[3].append(b2.ptr if b2 is not None else 0)
+                    g[4].append(tag)
+                except Exception as e:  # W2:558-560
+                    out[idx] = ProcessStatus("Exception: " + str(e))
         if groups:
-            be.sync_inputs()  # uploads made through torch are visible to the library's stream
+            be.sync_inputs()  # uploads made through torch are visible to the library's streams
         ok_status = ProcessStatus.Ok
         for (code, B, urgent), (idxs, p0, p1, p2, tags) in sorted(groups.items(), key=lambda kv: not kv[0][2]):  # the chain's first
             m = len(idxs)
@@ -456,10 +497,9 @@ class DagCholeskyWorker(ArmoniKWorker):
             ptr = np.empty((5, m), dtype=np.uint64)
             ptr[0], ptr[1], ptr[2], ptr[4] = p0, p1, p2, tags
             ptr[3] = np.arange(base, base + tb * m, tb, dtype=np.uint64)
-            order = None
+            slots = None
             if code == 4:  # POTRF: enqueued, the output tagged with its result id, info left in a device slot
-                outs = [handlers[i].first_expected_result() for i in idxs]
-                ptr[4] = [_tag_of(o) for o in outs]
+                ptr[4] = [_tag_of(tasks[i].expected_output_keys[0]) for i in idxs]
                 slots = (C.c_int * m)()
                 t0 = time.perf_counter()
                 rc = be.potrf_batch(B, m, ptr, slots)
@@ -474,7 +514,7 @@ class DagCholeskyWorker(ArmoniKWorker):
                     nsyrk = int(np.count_nonzero(ptr[2] == 0))
                 ptr[:3] = ptr[:3, order]
                 ptr[4] = ptr[4, order]
-                idxs = [idxs[int(o)] for o in order]
+                idxs = [idxs[o] for o in order.tolist()]
                 t0 = time.perf_counter()
                 rc = be.tile_batch(1 if code == 1 else 4, B, m, ptr, urgent)
                 opname = "TRSM" if code == 1 else ("SYRK" if nsyrk == m else "GEMM")
@@ -489,10 +529,20 @@ class DagCholeskyWorker(ArmoniKWorker):
                 for i in idxs:
                     out[i] = ProcessStatus(msg)
                 continue
-            for q, i in enumerate(idxs):
-                h = handlers[i]
+            if fast is not None:
                 try:
-                    oid = outs[q] if code == 4 else h.first_expected_result()
+                    oids = fast.complete_batch(tasks, idxs, results, DeviceBlob, res, base, tb, epoch, out, ok_status)
+                    if code == 4:
+                        self._deferred.extend(zip(oids, [int(v) for v in slots]))
+                    continue
+                except Exception:  # (a result that already has data ...: the loop below reports task by task what is left)
+                    pass
+            for q, i in enumerate(idxs):
+                if out[i] is not None:
+                    continue
+                h = handler(i)
+                try:
+                    oid = h.first_expected_result()
                     h.send_result(oid, DeviceBlob(res, q * tb, tb, epoch, base)).get()
                     if code == 4:
                         self._deferred.append((oid, int(slots[q])))
