@@ -203,6 +203,7 @@ def run_single(a) -> dict:
     res = ch.residual_plgsy(d, float(N), a.seed) if not a.no_check else None
     ch.CHAMELEON_Desc_Destroy(d)
     return {"elapsed": elapsed, "upd_ms": upd_ms, "upd_flops": upd_flops, "upd_launches": upd_launches,
+            "regimes": ch.last_potrf_regimes(),  # of the last (un-bracketed) step: the schedule the timed steps ran too
             "residual": res, "probe": probe, "kernel": kernel, "calibration": ch.calibration(),
             "counters": bool(lib_counters()), "unprofiled_ms": unprofiled * 1e3}
 
@@ -233,7 +234,8 @@ def run_multi(a) -> dict:
     beat("init")
     dist.init_process_group("gloo")
     beat("rendezvous")
-    P, Q = dd.grid_for(world)
+    grids = dd.candidate_grids(world)
+    P, Q = grids[0]
     eng = dd.HipEngine(a.N, a.tile, P, Q, rank, a.dtype, device=local)
     fallback = None
     if backend == "rccl":
@@ -257,6 +259,41 @@ def run_multi(a) -> dict:
     else:
         tr = dd.TorchTransport(dist, device=local)
         tr.install()
+    # MEASURE the grid, do not model it: one connecting and one timed factorisation on each candidate (4x2 and 2x4 for
+    # eight ranks; new descriptors, the same communicators), the timed steps on the faster.  Both times go into the line.
+    grid_probe = None
+    if len(grids) > 1:
+        grid_probe = {}
+        best = None
+        for (p2, q2) in grids:
+            e2 = eng if (p2, q2) == (P, Q) else dd.HipEngine(a.N, a.tile, p2, q2, rank, a.dtype, device=local)
+            tms = 0.0
+            for rep_ in range(2):  # the first connects the peers this grid talks to; the second is timed
+                e2.generate(float(a.N), a.seed)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                info = e2.potrf_tile()
+                torch.cuda.synchronize()
+                dist.barrier()
+                tms = (time.perf_counter() - t0) * 1e3
+                assert info == 0, info
+            tt = torch.tensor([tms], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            grid_probe[f"{p2}x{q2}"] = round(float(tt.item()), 3)
+            beat(f"grid{p2}x{q2}")
+            if best is None or float(tt.item()) < best[0]:
+                if best is not None and best[1] is not eng:
+                    best[1].destroy()
+                best = (float(tt.item()), e2, p2, q2)
+            elif e2 is not eng:
+                e2.destroy()
+                del e2
+        if best[1] is not eng:
+            eng.destroy()
+        _, eng, P, Q = best
+        grid_probe["chosen"] = f"{P}x{Q}"
+        torch.cuda.empty_cache()
     factor = eng.potrf_tile
     for w in range(max(1, a.warmup)):  # at least one: RCCL connects its peers on first use
         eng.generate(float(a.N), a.seed)
@@ -301,6 +338,8 @@ def run_multi(a) -> dict:
     stats["rank_update_tflops"] = [round(float(x[3]) / (float(x[0]) * 1e-3) / 1e12, 2) if float(x[0]) > 0 else None for x in per_rank]
     stats["calibration"] = ch.calibration()
     stats["counters"] = bool(lib_counters())
+    stats["regimes_rank0"] = ch.last_potrf_regimes()
+    stats["grid_probe"] = grid_probe
     beat("profiled")
     # device time of each rank's own schedule in the last step (HIP events on its streams): max and min over ranks --
     # their spread is the block-cyclic imbalance plus what each rank waited for tiles
@@ -487,7 +526,11 @@ def main() -> int:
             line["config"]["schedule_calibration"] = {"mfma_probe_tflops": [round(c[0], 2), round(c[2], 2)],
                                                       "diag_step_us": [round(c[1], 1), round(c[3], 1)],
                                                       # False: chol_init's probe left the counter-linked chain off (events only)
-                                                      "device_counters": r["counters"]}
+                                                      "device_counters": r["counters"],
+                                                      "pinned": os.environ.get("CHOLMI_CALIB")}
+            # which regime the walker picked for how many of the waves (it picks from the calibration above: two boxes may
+            # run two schedules -- this ties the number to the one it ran)
+            line["config"]["schedule_regimes"] = r["regimes"]
             # one extra step without the library's HIP-event brackets, beside the mean of the K bracketed ones
             line["unprofiled_ms"] = round(r["unprofiled_ms"], 3)
         if not a.no_worker_path:
@@ -513,7 +556,11 @@ def main() -> int:
         c = r["dist"]["calibration"]
         line["config"]["schedule_calibration"] = {"mfma_probe_tflops": [round(c[0], 2), round(c[2], 2)],
                                                   "diag_step_us": [round(c[1], 1), round(c[3], 1)],
-                                                  "device_counters": r["dist"]["counters"]}
+                                                  "device_counters": r["dist"]["counters"], "pinned": os.environ.get("CHOLMI_CALIB")}
+        line["config"]["schedule_regimes"] = r["dist"]["regimes_rank0"]
+        if r["dist"].get("grid_probe"):
+            # one timed factorisation per candidate grid ahead of the timed steps [ms, max over ranks]; the steps ran on "chosen"
+            line["config"]["grid_probe"] = r["dist"]["grid_probe"]
         if os.environ.get("CHOLMI_BENCH_HB"):
             line["launcher"] = "self"
     print(json.dumps(line), flush=True)

@@ -247,6 +247,19 @@ def last_potrf_stats() -> dict:
     return {"total_ms": t.value, "update_ms": u.value, "update_launches": n.value, "update_flops": f.value}
 
 
+REGIME_NAMES = ("paired", "plain", "halves", "counter_linked", "near_column", "flow", "yielding", "column_latency_form")
+
+
+def last_potrf_regimes() -> dict:
+    """How many waves of the last whole-matrix factorisation ran in which regime of the walker (chol_last_potrf_regimes):
+    paired / plain / halves / near_column partition the waves that have an update; the others are attributes."""
+    v, nt = (C.c_int * 8)(), C.c_int()
+    lib().chol_last_potrf_regimes(v, C.byref(nt))
+    d = {k: int(v[i]) for i, k in enumerate(REGIME_NAMES)}
+    d["waves"] = int(nt.value)
+    return d
+
+
 def mfma_probe(dtype: int = ChamRealDouble, waves_per_simd: int = 1) -> float:
     """TFLOP/s of a register-only MFMA stream on every CU (sustained matrix-core ceiling)."""
     r = C.c_double()

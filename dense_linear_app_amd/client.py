@@ -325,16 +325,14 @@ def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane
         retire_limit = int(os.environ.get("CHOLESKY_RETIRE_BYTES", str(24 << 30)))
         retire_q, retired_bytes, tile_bytes = deque(), 0, 8 * Bi * Bi
         can_retire = device_results and resultsClient is not None and hasattr(worker, "mark")
-        for k in range(Nb):
-            while can_retire and retired_bytes > retire_limit and retire_q:
-                mark, ids, nbytes = retire_q.popleft()
-                worker.wait_mark(mark)
-                resultsClient.delete_results_data(session_id, ids)
-                retired_bytes -= nbytes
+        superseded: Dict[int, list] = {0: [latest[bid[i][0]] for i in range(Nb)]} if can_retire else {}
+        # Submission order (every task is submitted after the tasks that produce its inputs, as C2:506-565 requires; the
+        # order among independent tasks is the client's to choose): POTRF(k+1) and the TRSMs of panel k+1 need column
+        # k+1 only, which the chain's update of wave k has just produced -- they go out BEFORE the bulk of wave k's
+        # update, so that the GPU runs the next panel while this thread is still writing the (many) payloads of that bulk.
+        def chain_of(k):
+            """POTRF(k,k) and TRSM(i,k), i > k: -> the outputs of the TRSMs"""
             kk = bid[k][k]
-            if can_retire:
-                gone = [latest[kk]]
-                gone.extend(latest[bid[i][j]] for i in range(k + 1, Nb) for j in range(k, i + 1))
             latest[kk] = submit_batch([(make_payload("POTRF", [latest[kk]], B), [latest[kk]])], 2)[0]
             counts["POTRF"] += 1
             Lkk = latest[kk]
@@ -344,7 +342,21 @@ def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane
             for i, o in zip(rows, outs):
                 latest[bid[i][k]] = o
             counts["TRSM"] += len(outs)
-            # column k+1 first and apart (the chain's tasks), then the rest of the wave's update
+            return outs
+
+        outs = chain_of(0) if Nb > 0 else []
+        for k in range(Nb):
+            while can_retire and retired_bytes > retire_limit and retire_q:
+                mark, ids, nbytes = retire_q.popleft()
+                worker.wait_mark(mark)
+                resultsClient.delete_results_data(session_id, ids)
+                retired_bytes -= nbytes
+            rows = range(k + 1, Nb)
+            # the versions this wave supersedes: column k's inputs (gone once the panel has run) and every tile it updates
+            gone_now = []
+            if can_retire:
+                gone_now = [v for v in superseded.pop(k, [])]
+            # column k+1 first and apart (the chain's tasks), then -- behind the next panel -- the rest of the wave's update
             k1 = k + 1
             items1, keys1, items, keys = [], [], [], []
             for i, Aik in zip(rows, outs):
@@ -362,13 +374,22 @@ def _run_waves_batched(N, B, Nb, session_id, latest, counts, submit_batch, plane
                 (keys1 if i == k1 else keys).append(row[i])
                 counts["GEMM"] += i - k - 1
                 counts["SYRK"] += 1
+            if can_retire:
+                gone_now.extend(latest[key] for key in keys1)
+                gone_now.extend(latest[key] for key in keys)
             for key, o in zip(keys1, submit_batch(items1, 2)):
                 latest[key] = o
+            nxt = []
+            if k1 < Nb:
+                if can_retire:  # (the inputs of the next panel: read by its POTRF / TRSMs only, retired with wave k+1)
+                    superseded[k1] = [latest[bid[i][k1]] for i in range(k1, Nb)]
+                nxt = chain_of(k1)
             for key, o in zip(keys, submit_batch(items)):
                 latest[key] = o
+            outs = nxt
             if can_retire:
-                nbytes = tile_bytes * len(gone)
-                retire_q.append((worker.mark(), gone, nbytes))
+                nbytes = tile_bytes * len(gone_now)
+                retire_q.append((worker.mark(), gone_now, nbytes))
                 retired_bytes += nbytes
         t_sub = time.perf_counter() - t0
         if device_results:

@@ -88,9 +88,24 @@ struct TaskExec {
   void *winv = nullptr;  // block inverses of the POTRF batches (two sets by parity of the POTRF count), chain stream only
   unsigned long long npotrf = 0;
   long long batches[2] = {0, 0}, cross_waits = 0;  // statistics: batches per stream, event waits between them
+  // A POTRF batch of ONE tile is not launched at once: the TRSM batch that follows it in every wave of the DAG (same L,
+  // outputs back to back) then goes out WITH it, pipelined over two streams as in the whole-matrix walker -- TRSM step s
+  // needs only the diagonal-block step s (launch_panel_pipelined), so a wave's chain is about POTRF + one TRSM step
+  // instead of POTRF + TRSM.  Anything else that comes first (another batch, a sync, a query) launches it alone.
+  struct Pending {
+    bool on = false;
+    int dtype = 0, mb = 0, slot = 0;
+    const void *a_in = nullptr;
+    void *a_out = nullptr;
+    unsigned long long version = 0;
+  } pend;
+  hipStream_t st_trsm = nullptr;       // the TRSM steps of a pipelined panel; joined back into the chain stream after it
+  hipEvent_t pev[36] = {};             // its per-step events (tiles up to 4096: 32 steps), then: pre, join
+  long long fused_panels = 0;
 };
 TaskExec tx;
 int tx_quiesce();
+double g_task_yield_factor = 6.0;  // CHOLMI_TASK_YIELD_FACTOR
 Ctx g;
 std::recursive_mutex g_mu;     // one ABI call at a time on the context
 std::mutex g_err_mu; // chol_last_error's buffer
@@ -175,6 +190,8 @@ int tx_init() {
   HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&tx.h_ring), tx.ring_bytes, hipHostMallocDefault));
   HIPCHECK(hipMalloc(reinterpret_cast<void **>(&tx.d_ring), tx.ring_bytes));
   HIPCHECK(hipMalloc(&tx.winv, 2 * g.r.winv_bytes));
+  tx.st_trsm = g.r.st[ST_TRSM];
+  for (int i = 0; i < 36; ++i) HIPCHECK(hipEventCreateWithFlags(&tx.pev[i], hipEventDisableTiming));
   tx.ready = true;
   return 0;
 }
@@ -183,14 +200,18 @@ void tx_destroy() {
   for (int s = 0; s < 2; ++s)
     for (int i = 0; i < TaskExec::EVPOOL; ++i)
       if (tx.ev[s][i]) (void)hipEventDestroy(tx.ev[s][i]);
+  for (int i = 0; i < 36; ++i)
+    if (tx.pev[i]) (void)hipEventDestroy(tx.pev[i]);
   (void)hipHostFree(tx.h_ring);
   (void)hipFree(tx.d_ring);
   (void)hipFree(tx.winv);
   tx = TaskExec();
 }
 // everything the executor has enqueued is complete afterwards; nothing is remembered
+int tx_flush_pending();
 int tx_quiesce() {
   if (!tx.ready || !tx.dirty) return 0;
+  if (int rc = tx_flush_pending()) return rc;
   HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));
   HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::BULK]));
   for (int s = 0; s < 2; ++s) {
@@ -921,6 +942,7 @@ int chol_init(int ncpu, int ngpu) {
   if (const char *e = getenv("CHOLMI_FLOW_FENCES")) cholmi::g_flow_fences = atoi(e);
   if (const char *e = getenv("CHOLMI_INTILE_FUSED")) cholmi::g_intile_fused = atoi(e);
   if (const char *e = getenv("CHOLMI_MIN_UNITS")) cholmi::g_min_units = atoi(e);
+  if (const char *e = getenv("CHOLMI_TASK_YIELD_FACTOR")) g_task_yield_factor = atof(e);
   HIPCHECK(hipMalloc(&g.d_acc, 2 * sizeof(double)));
   HIPCHECK(hipMalloc(&g.d_ytab, YTAB_ENTRIES * sizeof(int)));
   HIPCHECK(hipMemset(g.d_ytab, 0, YTAB_ENTRIES * sizeof(int)));
@@ -1128,12 +1150,90 @@ int chol_sync(void) {
 
 // ---------------------------------------------------------------- the tasks of one op class in one grouped launch
 // (the executor: TaskExec / tx_* above)
+
+// the pending POTRF (TaskExec::Pending) alone, as chol_potrf_batch would have launched it
+template <typename T>
+static int flush_pending_t() {
+  const TaskExec::Pending p = tx.pend;
+  tx.pend.on = false;
+  hipStream_t s = tx.st[TaskExec::CHAIN];
+  HIPCHECK(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), s));
+  HIPCHECK(hipMemcpyAsync(p.a_out, p.a_in, (size_t)p.mb * p.mb * sizeof(T), hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
+  T *wset = reinterpret_cast<T *>(tx_winv_set());
+  launch_potrf_tile<T>(s, reinterpret_cast<T *>(p.a_out), p.mb, wset, g.d_binfo + p.slot, 0, tile_sems());
+  forget_winv(p.a_out);
+  tx_remember_winv(p.a_out, p.version, p.mb, p.dtype, wset);
+  HIPCHECK(hipGetLastError());
+  void *outs[1] = {p.a_out};
+  return tx_commit(TaskExec::CHAIN, outs, 1, 0, 0);
+}
+namespace {
+int tx_flush_pending() {
+  if (!tx.ready || !tx.pend.on) return 0;
+  return tx.pend.dtype == CHOL_REAL_DOUBLE ? flush_pending_t<double>() : flush_pending_t<float>();
+}
+}  // namespace
+
+// The pending POTRF and the n TRSM tasks of its panel in one pipelined issue (kernels.hip: launch_panel_pipelined): the
+// diagonal-block steps on the chain stream, TRSM step s on the TRSM stream behind the event of step s; the TRSM stream
+// starts behind an event of the chain stream (it follows everything the chain stream follows) and is joined back into
+// it at the end, so that for the dependency tracker the whole panel is ONE batch of the chain stream.
+template <typename T>
+static int panel_fused_impl(int dtype, int mb, int n, const void *const *c_in, void *const *c_out) {
+  const TaskExec::Pending p = tx.pend;
+  tx.pend.on = false;
+  const int X = TaskExec::CHAIN, nbm = mb / MACRO;
+  hipStream_t sp = tx.st[X], st = tx.st_trsm;
+  const size_t tb = (size_t)mb * mb * sizeof(T), lb = (size_t)n * sizeof(void *);
+  size_t off = 0;
+  int rc = tx_take(2 * lb, &off);
+  if (rc) return rc;
+  char *hl = tx.h_ring + off, *dl = tx.d_ring + off;
+  memcpy(hl, c_in, lb);
+  memcpy(hl + lb, c_out, lb);
+  const void *const *ins[1] = {c_in};
+  rc = tx_follow(X, ins, 1, n);  // (the POTRF's own input was followed when it was stashed)
+  if (rc) return rc;
+  hipEvent_t ev_pre = tx.pev[34], ev_join = tx.pev[35];
+  HIPCHECK(hipEventRecord(ev_pre, sp));
+  HIPCHECK(hipStreamWaitEvent(st, ev_pre, 0));
+  // the private copies: the diagonal tile on the chain stream, the panel tiles on the TRSM stream (beside the first steps)
+  HIPCHECK(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), sp));
+  HIPCHECK(hipMemcpyAsync(p.a_out, p.a_in, tb, hipMemcpyDeviceToDevice, sp));
+  HIPCHECK(hipMemcpyAsync(dl, hl, 2 * lb, hipMemcpyHostToDevice, st));
+  launch_copy_ptrs(st, (const void *const *)dl, (void *const *)(dl + lb), n, (long)tb);
+  T *wset = reinterpret_cast<T *>(tx_winv_set());
+  launch_panel_pipelined<T>(sp, st, tx.pev, reinterpret_cast<T *>(p.a_out), mb, wset, g.d_binfo + p.slot, 0,
+                            reinterpret_cast<T *>(c_out[0]), (long)mb * mb, n, nullptr, nullptr, nullptr, 0, tile_sems());
+  (void)nbm;
+  HIPCHECK(hipEventRecord(ev_join, st));
+  HIPCHECK(hipStreamWaitEvent(sp, ev_join, 0));
+  forget_winv(p.a_out);
+  for (int t = 0; t < n; ++t) forget_winv(c_out[t]);
+  tx_remember_winv(p.a_out, p.version, mb, dtype, wset);
+  HIPCHECK(hipGetLastError());
+  ++tx.fused_panels;
+  void *outs1[1] = {p.a_out};
+  rc = tx_commit(X, outs1, 1, 0, 0);
+  if (rc) return rc;
+  return tx_commit(X, c_out, n, off, off + 2 * lb);
+}
+
 template <typename T>
 static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a, const void *const *b,
                            void *const *c_out, const unsigned long long *a_versions, int flags) {
   int rc = tx_init();
   if (rc) return rc;
   const bool update = op != CHOL_BATCH_TRSM;
+  if (tx.pend.on) {
+    // the TRSM batch of the pending POTRF's own panel: every task solves against that tile, outputs back to back
+    bool fuse = !update && tx.pend.dtype == dtype && tx.pend.mb == mb;
+    for (int t = 0; fuse && t < n; ++t)
+      fuse = a[t] == tx.pend.a_out && (t == 0 || (const char *)c_out[t] == (const char *)c_out[t - 1] + (size_t)mb * mb * sizeof(T));
+    if (fuse) return panel_fused_impl<T>(dtype, mb, n, c_in, c_out);
+    rc = tx_flush_pending();
+    if (rc) return rc;
+  }
   const int X = (!update || (flags & CHOL_BATCH_URGENT)) ? TaskExec::CHAIN : TaskExec::BULK;
   hipStream_t s = tx.st[X];
   const size_t tb = (size_t)mb * mb * sizeof(T), lb = (size_t)n * sizeof(void *);
@@ -1161,7 +1261,10 @@ static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *
     const int f = dtype == CHOL_REAL_DOUBLE ? 0 : 1;
     const double t_tile = 2.0 * mb * (double)mb * mb / (g.r.probe_tflops[f] * CHOLMI_UPDATE_EFF * 1e12);
     const double t_panel = g.r.diag_us[f] * 1e-6 * CHOLMI_STEP_FACTOR * (mb / MACRO);
-    const bool yield = X == TaskExec::BULK && g.r.probe_tflops[f] > 0 && n * t_tile < 3.0 * t_panel;
+    // (6 panel estimates, not the walker's 3: the task path's chain is POTRF, THEN the TRSM, THEN column k+1 -- about twice
+    // the walker's pipelined one -- and beside an update that does not yield its diagonal-block steps take 230-370 us
+    // instead of 50: profiles/r05_worker_path_trace_N16384_B512.txt)
+    const bool yield = X == TaskExec::BULK && g.r.probe_tflops[f] > 0 && n * t_tile < g_task_yield_factor * t_panel;
     launch_update_ptrs<T>(s, (const T *const *)d_cin, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, yield);
   } else {
     // TRSM: private copies, then runs of consecutive tasks with the same L and outputs laid out back to back as panels
@@ -1193,7 +1296,7 @@ static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *
 // POTRF of n HBM-resident tiles, each on its private copy, info per tile in a device slot (read after chol_sync)
 template <typename T>
 static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
-                            const unsigned long long *versions, int *slots) {
+                            const unsigned long long *versions, int *slots, bool defer) {
   int rc = tx_init();
   if (rc) return rc;
   const int X = TaskExec::CHAIN;
@@ -1203,9 +1306,21 @@ static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, v
     HIPCHECK(hipMalloc(&g.d_binfo, BINFO_SLOTS * sizeof(int)));
     HIPCHECK(hipMemset(g.d_binfo, 0, BINFO_SLOTS * sizeof(int)));
   }
+  rc = tx_flush_pending();
+  if (rc) return rc;
   const void *const *ins[1] = {a_in};
   rc = tx_follow(X, ins, 1, n);
   if (rc) return rc;
+  if (n == 1 && defer) {  // (see TaskExec::Pending: launched with the TRSM batch that follows, or alone by whatever comes first)
+    const int slot = (int)(g.binfo_next++ % BINFO_SLOTS);
+    slots[0] = slot;
+    tx.pend.on = true;
+    tx.pend.dtype = dtype, tx.pend.mb = mb, tx.pend.slot = slot;
+    tx.pend.a_in = a_in[0], tx.pend.a_out = a_out[0];
+    tx.pend.version = versions ? versions[0] : 0;
+    tx.dirty = true;
+    return 0;
+  }
   for (int t = 0; t < n; ++t) {
     const int slot = (int)(g.binfo_next++ % BINFO_SLOTS);
     slots[t] = slot;
@@ -1231,8 +1346,9 @@ int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *co
   if (n == 0) return 0;
   if (!a_in || !a_out || !slots) return fail(-4, "potrf_batch: NULL pointer list");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  const int rc = dtype == CHOL_REAL_DOUBLE ? potrf_batch_impl<double>(dtype, mb, n, a_in, a_out, versions, slots)
-                                           : potrf_batch_impl<float>(dtype, mb, n, a_in, a_out, versions, slots);
+  const bool defer = (flags & CHOL_BATCH_ASYNC) != 0;
+  const int rc = dtype == CHOL_REAL_DOUBLE ? potrf_batch_impl<double>(dtype, mb, n, a_in, a_out, versions, slots, defer)
+                                           : potrf_batch_impl<float>(dtype, mb, n, a_in, a_out, versions, slots, defer);
   if (rc) return rc;
   if (!(flags & CHOL_BATCH_ASYNC)) return tx_quiesce();
   return 0;
@@ -1242,6 +1358,7 @@ int chol_batch_info(int slot, int *info) {
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "batch_info before chol_init");
   if (!info || slot < 0 || slot >= BINFO_SLOTS || !g.d_binfo) return fail(-1, "batch_info: slot");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (int rc = tx_flush_pending()) return rc;
   if (tx.ready) HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));  // (every POTRF batch runs on the chain stream)
   HIPCHECK(hipMemcpy(info, g.d_binfo + slot, sizeof(int), hipMemcpyDeviceToHost));
   return 0;
@@ -1269,6 +1386,10 @@ int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, c
 
 int chol_batch_mark(unsigned long long *mark2) {
   if (!mark2) return fail(-1, "batch_mark: NULL");
+  {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int rc = tx_flush_pending()) return rc;
+  }
   mark2[0] = tx.seq[TaskExec::CHAIN], mark2[1] = tx.seq[TaskExec::BULK];
   return 0;
 }
@@ -1290,6 +1411,7 @@ int chol_batch_wait(const unsigned long long *mark2) {
 int chol_batch_stats(long long *out4) {
   if (!out4) return fail(-1, "batch_stats: NULL");
   out4[0] = tx.batches[TaskExec::CHAIN], out4[1] = tx.batches[TaskExec::BULK], out4[2] = tx.cross_waits, out4[3] = (long long)tx.prod.size();
+  if (getenv("CHOLMI_VERBOSE")) fprintf(stderr, "[cholmi] task executor: %lld panels issued pipelined (POTRF + its TRSM batch)\n", tx.fused_panels);
   return 0;
 }
 

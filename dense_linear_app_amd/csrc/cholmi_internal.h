@@ -194,7 +194,7 @@ template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles,
                             hipEvent_t ev_head = nullptr, const SyrkPipe *sy = nullptr, const int *wait_sem = nullptr,
-                            int wait_target = 0);
+                            int wait_target = 0, int *tile_sem = nullptr);
 
 template <typename T>
 void launch_col_update_small(hipStream_t s, T *C, const T *A, const T *B, int mb, int ntiles, long bsiz, int *done);

@@ -2723,9 +2723,12 @@ void launch_potrf_tile(hipStream_t s, T *tile, int mb, T *winv, int *d_info, int
 template <typename T>
 void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *lkk, int mb, T *winv,
                             int *d_info, int info_base, T *tiles, long bsiz, int ntiles, hipEvent_t ev_head,
-                            const SyrkPipe *sy, const int *wait_sem, int wait_target) {
+                            const SyrkPipe *sy, const int *wait_sem, int wait_target, int *tile_sem) {
   const int nbm = mb / MACRO;
   const bool pipe = sy && ntiles > 0;
+  // event-linked form with tile_sem (mb / 128 counters, 32 ints apart): the in-tile steps fused as in launch_potrf_tile
+  const bool fused_plain = !pipe && tile_sem && g_intile_fused && nbm > 1;
+  if (fused_plain) (void)hipMemsetAsync(tile_sem, 0, (size_t)nbm * 32 * sizeof(int), sp);
   // pipe: counters of this wave, one 128-byte slot each -- D[s] the diagonal-block step s, I[s] the in-tile
   // solve of step s (4 nr workgroups), H[s] the head tile's workgroups of TRSM step s, then `done`
   auto slot = [&](int i) { return sy->sem + 32 * i; };
@@ -2751,11 +2754,11 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
                                          d_info, info_base + s * MACRO, 1, g_dbg, g_ytab, s == 0 ? wait_sem : nullptr,
                                          wait_target, pipe ? slot(s) : nullptr);
     if (nr > 0 && !flow) {
-      if (pipe && g_intile_fused && nr * (2 * nr + 1) <= INTILE_FUSED_MAX) {
+      if ((pipe || fused_plain) && g_intile_fused && nr * (2 * nr + 1) <= INTILE_FUSED_MAX) {
         // solve and update of the step in one launch, the update's workgroups polling the solves' counter
         // (which the TRSM step's update on st polls too)
-        k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab, slot(nbm + s),
-                                                                     d_info);
+        k_intile_step<T><<<4 * nr + nr * (2 * nr + 1), 256, 0, sp>>>(lkk, mb, nbm, s, winv, g_ytab,
+                                                                     pipe ? slot(nbm + s) : tile_sem + 32 * s, d_info);
       } else {
         k_solve_small<T><<<4 * nr, 256, 0, sp>>>(lkk, 0, mb, nbm, s + 1, s, winv, T(1), g_ytab, nullptr, 0, nullptr,
                                                  pipe ? slot(nbm + s) : nullptr);
@@ -2797,9 +2800,9 @@ void launch_panel_pipelined(hipStream_t sp, hipStream_t st, hipEvent_t *ev, T *l
   if (ev_head) (void)hipEventRecord(ev_head, st);
 }
 template void launch_panel_pipelined<double>(hipStream_t, hipStream_t, hipEvent_t *, double *, int, double *,
-                                             int *, int, double *, long, int, hipEvent_t, const SyrkPipe *, const int *, int);
+                                             int *, int, double *, long, int, hipEvent_t, const SyrkPipe *, const int *, int, int *);
 template void launch_panel_pipelined<float>(hipStream_t, hipStream_t, hipEvent_t *, float *, int, float *, int *,
-                                            int, float *, long, int, hipEvent_t, const SyrkPipe *, const int *, int);
+                                            int, float *, long, int, hipEvent_t, const SyrkPipe *, const int *, int, int *);
 
 template <typename T>
 void launch_invert_diag(hipStream_t s, const T *tile, int mb, T *winv) {

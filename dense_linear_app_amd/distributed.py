@@ -45,6 +45,21 @@ def grid_for(nranks: int) -> Tuple[int, int]:
     return nranks // q, q
 
 
+def candidate_grids(nranks: int) -> list:
+    """The grids worth MEASURING for `nranks` GPUs: grid_for's and its transpose (4x2 and 2x4 for 8).  Which of the two is
+    faster depends on the links (the tall grid halves the panel part that crosses ONE link per wave, the wide one the
+    column-operand messages), and the model that prefers the tall one rests on an assumed bandwidth and an assumed
+    per-group latency (scripts/grid_model.py); with communication free the wide grid is the faster
+    (profiles/r04_rank_alone_grids.txt).  bench.py --gpus N therefore runs one warm-up factorisation on each and takes
+    the faster (config.grid_probe).  CHOLMI_GRID pins one."""
+    import os
+
+    p, q = grid_for(nranks)
+    if os.environ.get("CHOLMI_GRID") or p == q:
+        return [(p, q)]
+    return [(p, q), (q, p)]
+
+
 def owner_of(I: int, J: int, P: int, Q: int) -> int:
     return (I % P) * Q + (J % Q)
 
@@ -108,6 +123,7 @@ class HipEngine:
 
     def destroy(self) -> None:
         self.ch.CHAMELEON_Desc_Destroy(self.desc)
+        self.store = None
 
 
 # ------------------------------------------------------------------------------------------
