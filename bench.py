@@ -449,14 +449,15 @@ def launch_ranks(a) -> int:
                 p.wait()
     for t in threads:
         t.join(timeout=5)
-    for f in os.listdir(hb):
-        os.unlink(os.path.join(hb, f))
-    os.rmdir(hb)
-    if error:
+    if error:  # (the promised single JSON line first: nothing below may replace it with a traceback)
         line = {"metric": "fp64 TFLOP/s for NxN SPD Cholesky (N^3/3 flops / factorisation time)", "value": None,
                 "unit": "TFLOP/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup, "launcher": "self"}
         line.update(error)
         print(json.dumps(line), flush=True)
+    import shutil
+
+    shutil.rmtree(hb, ignore_errors=True)  # (a rank killed late can still be writing its heartbeat file)
+    if error:
         return 3
     json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcholmi.so")
+# (LIBCHOLMI_PATH: another build of the same library, for same-box A/B measurements -- scripts/ only)
+LIB_PATH = os.environ.get("LIBCHOLMI_PATH") or os.path.join(_HERE, "libcholmi.so")
 
 _lib = None
 

@@ -315,8 +315,9 @@ class ControlPlane:
         return True
 
     def _blocked_forever(self, t: _Task) -> bool:
+        # (a dependency whose data was deleted can never complete either: delete_results_data)
         need = [t.payload_id] + t.data_dependencies
-        return any(self._results[r].status == "aborted" for r in need)
+        return any(self._results[r].status in ("aborted", "deleted") for r in need)
 
     def _run(self, t: _Task) -> None:
         worker = self._workers.get(t.options.partition_id)
@@ -468,7 +469,8 @@ class ControlPlane:
                 t = self._tasks[tid]
                 if self._blocked_forever(t):
                     t.status = "error"
-                    t.output = ProcessStatus("a data dependency was aborted")
+                    gone = any(self._results[r].status == "deleted" for r in [t.payload_id] + t.data_dependencies)
+                    t.output = ProcessStatus("a data dependency was deleted" if gone else "a data dependency was aborted")
                     for k in t.expected_output_keys:
                         self._results[k].status = "aborted"
                     self._pending.remove(tid)

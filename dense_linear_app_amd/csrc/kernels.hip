@@ -1408,67 +1408,27 @@ __device__ __forceinline__ void invert_level(T *S, T (*Wd)[16 * 16], int w) {
   __syncthreads();
 }
 
-// Producer side of phase A: the 16 values of a just-published column as one burst of LDS
-// broadcast reads into registers of their own, issued without waiting; wait() before the first use.
-template <typename T>
-struct ColBurst;
-template <>
-struct ColBurst<double> {
-  typedef double v2_t __attribute__((ext_vector_type(2)));
-  v2_t c[8];
-  __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
-  // `anchor` is passed through untouched: whatever uses it afterwards (the critical update of the
-  // next pivot) cannot be scheduled above the burst
-  __device__ __forceinline__ void issue(unsigned col_addr, double &anchor) {
-    asm volatile(
-        "ds_read2_b64 %0, %9 offset1:1\n\t"
-        "ds_read2_b64 %1, %9 offset0:2 offset1:3\n\t"
-        "ds_read2_b64 %2, %9 offset0:4 offset1:5\n\t"
-        "ds_read2_b64 %3, %9 offset0:6 offset1:7\n\t"
-        "ds_read2_b64 %4, %9 offset0:8 offset1:9\n\t"
-        "ds_read2_b64 %5, %9 offset0:10 offset1:11\n\t"
-        "ds_read2_b64 %6, %9 offset0:12 offset1:13\n\t"
-        "ds_read2_b64 %7, %9 offset0:14 offset1:15"
-        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]),
-          "+v"(anchor)
-        : "v"(col_addr)
-        : "memory");
-  }
-  __device__ __forceinline__ void wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
-                 "+v"(c[6]), "+v"(c[7]) : : "memory");
-  }
-  // same, and not before `anchor` (a value of the pivot chain) has been produced
-  __device__ __forceinline__ void wait(double &anchor) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
-                 "+v"(c[6]), "+v"(c[7]), "+v"(anchor) : : "memory");
-  }
-};
-template <>
-struct ColBurst<float> {
-  typedef float v2_t __attribute__((ext_vector_type(2)));
-  v2_t c[8];
-  __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
-  __device__ __forceinline__ void issue(unsigned col_addr, float &anchor) {
-    asm volatile(
-        "ds_read2_b32 %0, %9 offset1:1\n\t"
-        "ds_read2_b32 %1, %9 offset0:2 offset1:3\n\t"
-        "ds_read2_b32 %2, %9 offset0:4 offset1:5\n\t"
-        "ds_read2_b32 %3, %9 offset0:6 offset1:7\n\t"
-        "ds_read2_b32 %4, %9 offset0:8 offset1:9\n\t"
-        "ds_read2_b32 %5, %9 offset0:10 offset1:11\n\t"
-        "ds_read2_b32 %6, %9 offset0:12 offset1:13\n\t"
-        "ds_read2_b32 %7, %9 offset0:14 offset1:15"
-        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]),
-          "+v"(anchor)
-        : "v"(col_addr)
-        : "memory");
-  }
-  __device__ __forceinline__ void wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
-                 "+v"(c[6]), "+v"(c[7]) : : "memory");
-  }
-};
+// v in the lanes of mask m, zero in the others (m a compile-time constant: two scalar moves, no compare)
+__device__ __forceinline__ double keep_lanes(double v, unsigned long long m) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int rl, rh;
+  asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4" : "=&v"(rl), "=&v"(rh) : "v"(lo), "v"(hi), "s"(m));
+  return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ float keep_lanes(float v, unsigned long long m) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  return r;
+}
+// one LDS store from the lanes of mask m only (the wave runs with all lanes active around it): no compare, no branch
+template <int OFF>
+__device__ __forceinline__ void lds_store_lanes(unsigned addr, double v, unsigned long long m) {
+  asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(v), "s"(m), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_store_lanes(unsigned addr, float v, unsigned long long m) {
+  asm volatile("s_mov_b64 exec, %2\n\tds_write_b32 %0, %1 offset:%3\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(v), "s"(m), "n"(OFF) : "memory");
+}
 
 // Consumer side of phase A: fetch column `jj` of the 16x16 factor (16 values), 1/pivot and the
 // publication counter in ONE LDS round trip and retry until the counter says the column was
@@ -1648,63 +1608,45 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
         int lane_ = lane, lo_ = lo;
         asm volatile("" : "+v"(lane_), "+v"(lo_));
         if (w == 0) {
-          T dd[NB];
-          const T *Dp = S + db_off(p, p) + lo_;
+          // The 16x16 block lives in ONE MFMA accumulator, spread over all 64 lanes (lane (hi, lo) holds column lo
+          // of the rows drow(lane, 0..3)), as E = -A and as the FULL symmetric matrix: row jj of it -- the column
+          // being eliminated, indexed by lo -- then sits in one register of the sixteen lanes of group K, which is
+          // exactly where the 16x16x4 MFMA wants both operands of a rank-1 update in k-slot K.  A pivot is:
+          // read the diagonal entry (v_readlane), v_rsq + Goldschmidt, scale that register, zero the other lanes,
+          // ONE MFMA  E += a a^T  -- about 15 instructions on the way to the next pivot instead of the 58 of the
+          // one-row-per-lane form (16 useful lanes, 14 FMAs per pivot for the trailing columns), which is what an
+          // in-order wave pays for.  Same values bit for bit: the scaled column is A * (h + h) as before, the MFMA
+          // with three zero k-slots is fma(-a_i, a_c, A(i,c)), and an update of E = -A rounds as the update of A does.
+          using acc_t = typename Tr<T>::acc_t;
+          const int hi_ = lane_ >> 4;
+          acc_t E;
+          {
+            const T *Dp = S + db_off(p, p);
 #pragma unroll
-          for (int jj = 0; jj < NB; ++jj) dd[jj] = Dp[jj * DB_LD];
-          int bad = 0;
-          // Software-pipelined by hand.  Column jj-1's updates of the columns c >= jj+1 have a
-          // whole iteration of slack (only its update of column jj is on the way to the next
-          // pivot, and that one is done straight from the lane by v_readlane): their multipliers
-          // are fetched from the column just published -- one burst of LDS broadcast reads into
-          // their own registers, not waited for -- and applied a few at a time BETWEEN the
-          // dependent steps of the next column's pivot chain, where an in-order wave would
-          // otherwise idle.  (Left to the compiler under the 256-VGPR cap, the fetch degenerated
-          // into six serial read-wait-use round trips per column ahead of the next pivot.)
-          ColBurst<T> prev;
-#define DEFER(k)                                                     \
-  do {                                                               \
-    constexpr int c_ = jj + 1 + (k);                                 \
-    if constexpr (jj >= 1 && c_ < NB && !(sizeof(T) == 8 && (k) == 0)) dd[c_] -= dd[jj - 1] * prev.at(c_); \
-  } while (0)
-          // fp64: the pivot chain proper is  d -> v_rsq -> g, e, (g, h), e, h  and then STRAIGHT to the next
-          // pivot:  d' = x - u^2,  u = (2a) h = a / sqrt(d)  (h = 1 / (2 sqrt(d)); x = A(jj+1,jj+1) and
-          // a = A(jj+1,jj) before the scaling, both in lane jj+1) -- the square root, the scaled column, its
-          // selects and the rank-1 update of column jj+1 (whose lane jj+1 nobody reads any more) are off the
-          // chain, and the next column's v_rsq is already in flight while they issue.  u is the very value
-          // the scaled column holds in that lane (2h is exact), so the factor is bit for bit what the
-          // straightforward order gives.
-          double dcur = 0, rcur = 0;
-          T a2n = T(0);  // 2 a, a = the unscaled column about to be eliminated
-          if constexpr (sizeof(T) == 8) {
-            dcur = rlane(dd[0], 0);
-            rcur = __builtin_amdgcn_rsq(dcur);
-            a2n = dd[0] + dd[0];
+            for (int reg = 0; reg < 4; ++reg) {
+              const int i = Tr<T>::drow(lane_, reg);
+              E[reg] = -Dp[(i >= lo_) ? i + lo_ * DB_LD : lo_ + i * DB_LD];
+            }
           }
+          int bad = 0;
           static_for<0, NB>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
-            T d;
-            if constexpr (sizeof(T) == 8) d = (T)dcur;
-            else d = rlane(dd[jj], jj);
+            constexpr int R = (sizeof(T) == 8) ? jj / 4 : jj % 4, K = (sizeof(T) == 8) ? jj % 4 : jj / 4;
+            // the lanes of group K below the diagonal: the multipliers L(lo, jj), lo > jj
+            constexpr unsigned long long M = (0xFFFFull & ~((2ull << jj) - 1ull)) << (16 * K);
+            const T d = -rlane(E[R], 16 * K + jj);
             if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
-            T sq, rinv;
+            // row jj of A beyond the diagonal, zero in every other lane -- selected AHEAD of the chain: the MFMA must
+            // not read a register an inline-asm instruction has just written (the compiler inserts the two wait
+            // states a VALU result needs before an MFMA reads it only behind instructions it knows)
+            const T Em = keep_lanes(-E[R], M);
+            T sq, rinv, a;
             if constexpr (sizeof(T) == 8) {
-              // PIN ties a chain value and the deferred results just produced into one (empty) asm:
-              // what follows in the chain cannot be scheduled above them, so the interleaving below
-              // is the issue order (the scheduler otherwise packs the dependent chain first and the
-              // fourteen independent FMAs behind it, which an in-order wave then executes in series)
-#define PIN2(x, k0, k1)                                                                                  \
-  do {                                                                                                   \
-    constexpr int a_ = jj + 1 + (k0), b_ = jj + 1 + (k1);                                                \
-    if constexpr (jj >= 1 && b_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]), "+v"(dd[b_]));           \
-    else if constexpr (jj >= 1 && a_ < NB) asm volatile("" : "+v"(x), "+v"(dd[a_]));                    \
-    else asm volatile("" : "+v"(x));                                                                     \
-  } while (0)
-              const double r = rcur;
               // +Inf passes `d > 0` in LAPACK too (dpotf2: sqrt(Inf) = Inf, the column is scaled by 1/Inf = 0,
               // info stays 0).  v_rsq(Inf) = 0; with the product d r taken on min(d, DBL_MAX) the iteration
               // stays at g = h = 0 (instead of Inf * 0 = NaN), so 1/pivot = 0 and the next pivot is left
               // alone, as there; only sqrt(d) itself needs the select below
+              const double r = __builtin_amdgcn_rsq((double)d);
               const double dm = __builtin_fmin((double)d, 1.7976931348623157e308);
               double g = dm * r, h = 0.5 * r;
               double e = __builtin_fma(-h, g, 0.5);
@@ -1712,64 +1654,42 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
               h = __builtin_fma(h, e, h);
               e = __builtin_fma(-h, g, 0.5);
               h = __builtin_fma(h, e, h);
-              // (column jj-1's update of column jj+1 was applied from the lane at the end of the last
-              // iteration: the burst of LDS reads behind column jj-1, issued just ahead of this chain, is
-              // not on the way to the next pivot)
-              if constexpr (jj + 1 < NB) {
-                const double u = (double)a2n * h;  // = a (2h) = a / sqrt(d), rounded as the scaled column is
-                const double tn = __builtin_fma(-u, u, (double)dd[jj + 1]);
-                dcur = rlane(tn, jj + 1);
-                rcur = __builtin_amdgcn_rsq(dcur);
-                PIN2(rcur, 1, 2);  // the next column's v_rsq issues here, ahead of everything below
-              }
-              g = __builtin_fma(g, e, g);
-              if constexpr (jj >= 1) prev.wait(g);
-              DEFER(1); DEFER(2); DEFER(3); PIN2(g, 1, 2);
-              const double cc = __builtin_fma(-g, g, (double)d);
               rinv = (T)(h + h);
-              DEFER(4); DEFER(5); DEFER(6); PIN2(rinv, 4, 5);
+              a = Em * rinv;
+              if constexpr (jj + 1 < NB) E = Tr<T>::mfma(a, a, E);
+              // off the chain, behind the MFMA: the square root itself
+              g = __builtin_fma(g, e, g);
+              const double cc = __builtin_fma(-g, g, (double)d);
               sq = (T)__builtin_fma(cc, h, g);
-              DEFER(7); DEFER(8); DEFER(9); DEFER(10); DEFER(11); DEFER(12); DEFER(13);
               if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0)
                 sq = (T)__builtin_huge_val();
-#undef PIN2
             } else {
-              if constexpr (jj >= 1) prev.wait();
-              DEFER(0); DEFER(1); DEFER(2); DEFER(3); DEFER(4); DEFER(5); DEFER(6);
-              DEFER(7); DEFER(8); DEFER(9); DEFER(10); DEFER(11); DEFER(12); DEFER(13);
               sqrt_rsqrt(d, sq, rinv);
+              a = Em * rinv;
+              if constexpr (jj + 1 < NB) E = Tr<T>::mfma(a, a, E);
             }
-            dd[jj] = (lo_ == jj) ? sq : dd[jj] * rinv;
-            // every lane stores (lanes 16-63 hold copies of rows 0-15; 1/pivot and the counter are
-            // wave-uniform): same address, same value -- no exec-mask region on the critical chain
-            Lc[jj * NB + lo_] = dd[jj];
+            // column jj of the factor from the sixteen lanes of group K (rows lo >= jj; zeros above, never read);
+            // 1/pivot and the counter are wave-uniform: every lane stores them -- same address, same value
+            lds_store_lanes<jj * NB * (int)sizeof(T)>((unsigned)(size_t)(Lc + lo_), (lo_ == jj) ? sq : a, 0xFFFFull << (16 * K));
             Lr[jj] = rinv;
             // DS operations of one wave execute in order: the flag lands after the column
             asm volatile("" ::: "memory");
             __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
-            if constexpr (jj + 2 < NB) prev.issue((unsigned)(size_t)Lc + jj * NB * (unsigned)sizeof(T), dd[jj]);
-            // column jj+1 by column jj, L(jj+1, jj) straight from the lane (fp32: this is the way to the next
-            // pivot; fp64: the rows below it only)
-            if constexpr (jj + 1 < NB) {
-              dd[jj + 1] -= dd[jj] * rlane(dd[jj], jj + 1);
-              if constexpr (sizeof(T) == 8 && jj + 2 < NB) {
-                a2n = dd[jj + 1] + dd[jj + 1];
-                dd[jj + 2] -= dd[jj] * rlane(dd[jj], jj + 2);  // (what DEFER(0) of the next iteration would do, early)
-              }
-            }
           });
-#undef DEFER
           if (bad) {
             if (lane_ == 0) {
               atomicCAS(info, 0, info_base + j0 + bad);
               failed = 1;
             }
-          } else if (lane_ < NB) {
+          } else {
+            // the factor of the diagonal block back into the block image (lower triangle), from the published columns
             T *Dw = S + db_off(p, p) + lo_;
 #pragma unroll
-            for (int jj = 0; jj < NB; ++jj)
-              if (jj <= lane_) Dw[jj * DB_LD] = dd[jj];
+            for (int q = 0; q < 4; ++q) {
+              const int c = 4 * hi_ + q;
+              if (lo_ >= c) Dw[c * DB_LD] = L.Lcol[c * NB + lo_];
+            }
           }
         } else {
           const int myrow = j0 + NB + 64 * (w - 1) + lane_;

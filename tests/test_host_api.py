@@ -191,6 +191,22 @@ def test_a_crashing_batch_keeps_the_books_of_tasks_that_had_already_sent_their_r
     assert all(tc.get_task_output(t) == ak.ProcessStatus.Ok for t in tids)
 
 
+def test_a_task_that_depends_on_deleted_data_fails_instead_of_waiting_for_ever():
+    """ResultsClient.delete_results_data leaves the metadata with status "deleted"; a task submitted against it can never
+    become ready -- it must end in error (and its outputs aborted), not stay pending (advisor, round 4)."""
+    plane, sid = _plane_with(DagCholeskyWorker(backend=OracleTileBackend()))
+    rc, tc = ak.ResultsClient(plane), ak.TasksClient(plane)
+    ids = rc.create_results_metadata(sid, ["o", "p", "a"])
+    rc.upload_result_data(sid, ids["a"], (4 * np.eye(4)).tobytes())
+    rc.upload_result_data(sid, ids["p"], '{"op":"POTRF","B":4,"in":"%s"}' % ids["a"])
+    rc.delete_results_data(sid, [ids["a"]])
+    (tid,) = tc.submit_tasks(sid, [ak.TaskCreation(ids["p"], [ids["o"]], [ids["a"]])], client.default_task_options())
+    out = tc.get_task_output(tid)
+    assert out is not None and out != ak.ProcessStatus.Ok and "deleted" in str(out.details if hasattr(out, "details") else out)
+    with pytest.raises(Exception):
+        ak.EventsClient(plane).wait_for_result_availability(sid, [ids["o"]])
+
+
 def test_client_dag_default_case_matches_golden():
     """C1/C2 default N=12, B=4: 3 waves, 3/3/3/1 tasks; factor equals the committed fixture."""
     res = client.run_cholesky_dag(12, 4, worker=DagCholeskyWorker(backend=OracleTileBackend()))
