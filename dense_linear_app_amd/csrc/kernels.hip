@@ -1430,104 +1430,39 @@ __device__ __forceinline__ void lds_store_lanes(unsigned addr, float v, unsigned
   asm volatile("s_mov_b64 exec, %2\n\tds_write_b32 %0, %1 offset:%3\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(v), "s"(m), "n"(OFF) : "memory");
 }
 
-// Consumer side of phase A: fetch column `jj` of the 16x16 factor (16 values), 1/pivot and the
-// publication counter in ONE LDS round trip and retry until the counter says the column was
-// complete when the reads were issued (DS operations execute in order, the counter is read first
-// and written last, so a satisfied counter vouches for the data behind it).  One opaque instruction
-// sequence on purpose: written as a C loop, sixteen unrolled copies of it gave the register allocator
-// a control-flow graph on which the kernel needed 400 VGPRs instead of 256.  Bounded (the producer
-// needs ~1 us per column even beside a running update; the bound is ~0.5 s of polling -- two processes
-// time-sliced on one GPU were seen to exceed a 1 ms bound): on giving up it stores
-// a value other than 0 / 1 into DiagLds::failed, which the kernel turns into info = INT_MAX after
-// the panel's barrier -- a logic error shows up as a loud failure, never as a hung GPU or a
-// silently wrong factor.  (Returning a flag instead and testing it in C++ put the kernel back over
-// the register limit.)
-template <typename T>
-struct ColFetch;
-template <>
-struct ColFetch<double> {
-  typedef double v2_t __attribute__((ext_vector_type(2)));
-  v2_t c[8];
-  double rinv;
-  __device__ __forceinline__ double at(int i) const { return c[i >> 1][i & 1]; }
-  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
-                                        unsigned failed_addr) {
-    int v, n = 0x3fffff;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %11\n\t"
-        "ds_read2_b64 %1, %12 offset1:1\n\t"
-        "ds_read2_b64 %2, %12 offset0:2 offset1:3\n\t"
-        "ds_read2_b64 %3, %12 offset0:4 offset1:5\n\t"
-        "ds_read2_b64 %4, %12 offset0:6 offset1:7\n\t"
-        "ds_read2_b64 %5, %12 offset0:8 offset1:9\n\t"
-        "ds_read2_b64 %6, %12 offset0:10 offset1:11\n\t"
-        "ds_read2_b64 %7, %12 offset0:12 offset1:13\n\t"
-        "ds_read2_b64 %8, %12 offset0:14 offset1:15\n\t"
-        "ds_read_b64 %9, %13\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_gt_i32_e32 vcc, %14, %0\n\t"
-        "s_cbranch_vccz 2f\n\t"
-        "s_sub_u32 %10, %10, 1\n\t"
-        "s_cmp_eq_u32 %10, 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 1b\n\t"
-        "3:\n\t"
-        "ds_write_b32 %15, %15\n\t"
-        "2:"
-        : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
-          "=&v"(c[7]), "=&v"(rinv), "+s"(n)
-        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target), "v"(failed_addr)
-        : "vcc", "scc", "memory");
-  }
-};
-template <>
-struct ColFetch<float> {
-  typedef float v2_t __attribute__((ext_vector_type(2)));
-  v2_t c[8];
-  float rinv;
-  __device__ __forceinline__ float at(int i) const { return c[i >> 1][i & 1]; }
-  __device__ __forceinline__ void fetch(unsigned flag_addr, unsigned col_addr, unsigned rinv_addr, int target,
-                                        unsigned failed_addr) {
-    int v, n = 0x3fffff;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %11\n\t"
-        "ds_read2_b32 %1, %12 offset1:1\n\t"
-        "ds_read2_b32 %2, %12 offset0:2 offset1:3\n\t"
-        "ds_read2_b32 %3, %12 offset0:4 offset1:5\n\t"
-        "ds_read2_b32 %4, %12 offset0:6 offset1:7\n\t"
-        "ds_read2_b32 %5, %12 offset0:8 offset1:9\n\t"
-        "ds_read2_b32 %6, %12 offset0:10 offset1:11\n\t"
-        "ds_read2_b32 %7, %12 offset0:12 offset1:13\n\t"
-        "ds_read2_b32 %8, %12 offset0:14 offset1:15\n\t"
-        "ds_read_b32 %9, %13\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_gt_i32_e32 vcc, %14, %0\n\t"
-        "s_cbranch_vccz 2f\n\t"
-        "s_sub_u32 %10, %10, 1\n\t"
-        "s_cmp_eq_u32 %10, 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 1b\n\t"
-        "3:\n\t"
-        "ds_write_b32 %15, %15\n\t"
-        "2:"
-        : "=&v"(v), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
-          "=&v"(c[7]), "=&v"(rinv), "+s"(n)
-        : "v"(flag_addr), "v"(col_addr), "v"(rinv_addr), "s"(target), "v"(failed_addr)
-        : "vcc", "scc", "memory");
-  }
-};
+// Consumer side of phase A: wait until an LDS word is no longer zero (DS operations of the producing wave execute in order and
+// the flag is written last, so a raised flag vouches for the data stored before it).  One opaque instruction sequence
+// on purpose: written as a C loop, the unrolled copies gave the register allocator a control-flow graph on which the
+// kernel needed 400 VGPRs instead of 256.  Bounded (the producer needs ~0.1 us per column; the bound is ~0.5 s of
+// polling -- two processes time-sliced on one GPU were seen to exceed a 1 ms bound): on giving up it stores a value
+// other than 0 / 1 into DiagLds::failed, which the kernel turns into info = INT_MAX after the panel's barrier -- a
+// logic error shows up as a loud failure, never as a hung GPU or a silently wrong factor.  The "memory" clobber keeps
+// the loads of the data behind the flag below it.
+__device__ __forceinline__ void lds_wait_flag(unsigned flag_addr, unsigned failed_addr) {
+  int v, n = 0x3fffff;
+  asm volatile(
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_eq_u32_e32 vcc, 0, %0\n\t"
+      "s_cbranch_vccz 2f\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_eq_u32 %1, 0\n\t"
+      "s_cbranch_scc0 1b\n\t"
+      "ds_write_b32 %3, %3\n\t"
+      "2:"
+      : "=&v"(v), "+s"(n)
+      : "v"(flag_addr), "v"(failed_addr)
+      : "vcc", "scc", "memory");
+}
 
 template <typename T>
 struct DiagLds {
   T S[DB_NP * (DB_NP + 1) / 2 * DB_SZ];
   T Wd[DB_NP][16 * 16];
-  T Lcol[16 * 16];  // phase A: the finished columns of the 16x16 factor being built ...
-  T Lrinv[16];      // ... the reciprocals of its pivots ...
-  int colready;     // ... and how many columns have been published (16 p + columns of panel p)
+  T Lrinv[16];      // phase A: MINUS the reciprocals of the pivots of the 16x16 factor being built (its columns go
+                    // straight into the block image S).  Cleared to +0 between panels: -1/sqrt(d) is never +0 (it is
+                    // negative, -0 for d = +Inf, NaN or -Inf for a bad pivot), so the slot is also the column's flag
   int failed;
 };
 
@@ -1579,10 +1514,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
     }
   }
   if constexpr (!FLOW) {
-    if (t == 0) {
-      failed = 0;
-      L.colready = 0;
-    }
+    if (t < 16) L.Lrinv[t] = T(0);
+    if (t == 0) failed = 0;
     __syncthreads();
   }
   if (ph && t == 0) ph[0] = PH_NOW();  // loaded
@@ -1599,9 +1532,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
         // LDS pointers with an opaque base: the 272 constant addresses below then encode as one
         // base register + immediate offsets instead of one hoisted VGPR each
         typedef __attribute__((address_space(3))) T lds_t;
-        lds_t *Lc = (lds_t *)L.Lcol, *Lr = (lds_t *)L.Lrinv;
+        lds_t *Lc = (lds_t *)(S + db_off(p, p)), *Lr = (lds_t *)L.Lrinv;  // column jj of the factor: Lc + jj * DB_LD
         asm volatile("" : "+v"(Lc), "+v"(Lr));
-        const int fbase = NB * p;
         // lane ids made opaque per panel: otherwise every lane mask, select and address of the
         // unrolled column code below is hoisted out of the panel loop and kept in registers for
         // its whole length (that alone cost > 100 VGPRs and most of the SGPR spills)
@@ -1612,40 +1544,57 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
           // of the rows drow(lane, 0..3)), as E = -A and as the FULL symmetric matrix: row jj of it -- the column
           // being eliminated, indexed by lo -- then sits in one register of the sixteen lanes of group K, which is
           // exactly where the 16x16x4 MFMA wants both operands of a rank-1 update in k-slot K.  A pivot is:
-          // read the diagonal entry (v_readlane), v_rsq + Goldschmidt, scale that register, zero the other lanes,
-          // ONE MFMA  E += a a^T  -- about 15 instructions on the way to the next pivot instead of the 58 of the
-          // one-row-per-lane form (16 useful lanes, 14 FMAs per pivot for the trailing columns), which is what an
-          // in-order wave pays for.  Same values bit for bit: the scaled column is A * (h + h) as before, the MFMA
-          // with three zero k-slots is fma(-a_i, a_c, A(i,c)), and an update of E = -A rounds as the update of A does.
+          // read the diagonal entry (v_readlane), v_rsq + Goldschmidt, scale that register (zero in the other
+          // lanes), ONE MFMA  E += a a^T , three LDS stores (the column into the block image, -1/pivot, the
+          // column's flag) -- about 30 instructions instead of the 58 of the one-row-per-lane form (16 useful
+          // lanes, 14 FMAs per pivot for the trailing columns), which is what an in-order wave pays for.  The
+          // square roots themselves (the diagonal of the factor) wait for the end of the
+          // panel: rows and columns <= jj of E are never touched again (a is zero there), so the diagonal of E still
+          // holds every pivot then, and sixteen lanes take the sixteen roots at once.  Same values bit for bit: the
+          // scaled column is A * (h + h) as before, the MFMA with three zero k-slots is fma(-a_i, a_c, A(i,c)), an
+          // update of E = -A rounds as the update of A does, and the root of a lane is the sequence the wave-uniform
+          // code ran.
           using acc_t = typename Tr<T>::acc_t;
           const int hi_ = lane_ >> 4;
           acc_t E;
-          {
-            const T *Dp = S + db_off(p, p);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int i = Tr<T>::drow(lane_, reg);
-              E[reg] = -Dp[(i >= lo_) ? i + lo_ * DB_LD : lo_ + i * DB_LD];
-            }
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = Tr<T>::drow(lane_, reg);
+            E[reg] = -Lc[max(i, lo_) + min(i, lo_) * DB_LD];  // (the block image holds the lower triangle)
           }
-          int bad = 0;
+          // The next pivot does not wait for the MFMA: d' = A(jj+1,jj+1) - u^2 with u = A(jj+1,jj) / sqrt(d), both
+          // entries read (v_readlane) from E as the PREVIOUS update left it -- the value the MFMA puts on the diagonal,
+          // bit for bit (same product, same fma).  So the scalar chain rsq -> Goldschmidt -> u -> d' -> rsq ... and the
+          // chain MFMA -> row -> scale -> MFMA run side by side instead of in series.  The order of issue is forced
+          // (ORDER: an empty asm that ties values together; what produces them is above it, what uses them below) --
+          // the wave issues in order, and the compiler's own order put the reads of E behind the whole scalar chain
+          // and the next pivot behind the vector work (261 cycles per pivot against 175: scripts/exp/rank1_probe2.hip).
+          T dcur = -rlane(E[0], 0);
           static_for<0, NB>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
             constexpr int R = (sizeof(T) == 8) ? jj / 4 : jj % 4, K = (sizeof(T) == 8) ? jj % 4 : jj / 4;
             // the lanes of group K below the diagonal: the multipliers L(lo, jj), lo > jj
             constexpr unsigned long long M = (0xFFFFull & ~((2ull << jj) - 1ull)) << (16 * K);
-            const T d = -rlane(E[R], 16 * K + jj);
-            if (bad == 0 && !(d > T(0))) bad = jj + 1;  // wave-uniform (d is scalar)
-            // row jj of A beyond the diagonal, zero in every other lane -- selected AHEAD of the chain: the MFMA must
-            // not read a register an inline-asm instruction has just written (the compiler inserts the two wait
-            // states a VALU result needs before an MFMA reads it only behind instructions it knows)
-            const T Em = keep_lanes(-E[R], M);
-            T sq, rinv, a;
+            const T d = dcur;
+            T rinvn;                 // -1 / sqrt(d)
+            T Em, as = T(0), xs = T(0);
+            // what the rest of the pivot needs of E (as the previous MFMA left it): row jj beyond the diagonal, zero in
+            // every other lane (selected ahead of the product: the MFMA must not read a register an inline-asm
+            // instruction has just written -- the compiler inserts the wait states a VALU result needs before an MFMA
+            // reads it only behind instructions it knows), -A(jj+1, jj) and -A(jj+1, jj+1)
+            auto reads = [&]() {
+              Em = keep_lanes(E[R], M);
+              if constexpr (jj + 1 < NB) {
+                constexpr int R1 = (sizeof(T) == 8) ? (jj + 1) / 4 : (jj + 1) % 4, K1 = (sizeof(T) == 8) ? (jj + 1) % 4 : (jj + 1) / 4;
+                as = rlane(E[R], 16 * K + jj + 1);
+                xs = rlane(E[R1], 16 * K1 + jj + 1);
+              }
+            };
             if constexpr (sizeof(T) == 8) {
               // +Inf passes `d > 0` in LAPACK too (dpotf2: sqrt(Inf) = Inf, the column is scaled by 1/Inf = 0,
               // info stays 0).  v_rsq(Inf) = 0; with the product d r taken on min(d, DBL_MAX) the iteration
               // stays at g = h = 0 (instead of Inf * 0 = NaN), so 1/pivot = 0 and the next pivot is left
-              // alone, as there; only sqrt(d) itself needs the select below
+              // alone, as there; only sqrt(d) itself needs a select (below, at the end of the panel)
               const double r = __builtin_amdgcn_rsq((double)d);
               const double dm = __builtin_fmin((double)d, 1.7976931348623157e308);
               double g = dm * r, h = 0.5 * r;
@@ -1653,75 +1602,137 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
               g = __builtin_fma(g, e, g);
               h = __builtin_fma(h, e, h);
               e = __builtin_fma(-h, g, 0.5);
+              asm volatile("" : "+v"(e), "+v"(h));                       // ORDER: the chain up to here ...
+              reads();
+              asm volatile("" : "+v"(e), "+v"(Em), "+s"(as), "+s"(xs));  // ... the reads of E (the previous MFMA has had ~70 cycles) ...
               h = __builtin_fma(h, e, h);
-              rinv = (T)(h + h);
-              a = Em * rinv;
-              if constexpr (jj + 1 < NB) E = Tr<T>::mfma(a, a, E);
-              // off the chain, behind the MFMA: the square root itself
-              g = __builtin_fma(g, e, g);
-              const double cc = __builtin_fma(-g, g, (double)d);
-              sq = (T)__builtin_fma(cc, h, g);
-              if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0)
-                sq = (T)__builtin_huge_val();
+              rinvn = (T)(-h - h);
             } else {
+              T sq, rinv;
               sqrt_rsqrt(d, sq, rinv);
-              a = Em * rinv;
-              if constexpr (jj + 1 < NB) E = Tr<T>::mfma(a, a, E);
+              asm volatile("" : "+v"(rinv));
+              reads();
+              asm volatile("" : "+v"(rinv), "+v"(Em), "+s"(as), "+s"(xs));
+              rinvn = -rinv;
             }
-            // column jj of the factor from the sixteen lanes of group K (rows lo >= jj; zeros above, never read);
-            // 1/pivot and the counter are wave-uniform: every lane stores them -- same address, same value
-            lds_store_lanes<jj * NB * (int)sizeof(T)>((unsigned)(size_t)(Lc + lo_), (lo_ == jj) ? sq : a, 0xFFFFull << (16 * K));
-            Lr[jj] = rinv;
-            // DS operations of one wave execute in order: the flag lands after the column
-            asm volatile("" ::: "memory");
-            __hip_atomic_store(&L.colready, fbase + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (jj + 1 < NB) {
+              const T u = as * rinvn;
+              if constexpr (sizeof(T) == 8) dcur = __builtin_fma(-u, u, -xs);
+              else dcur = __builtin_fmaf(-u, u, -xs);
+            }
+            T a = Em * rinvn;  // (-A)(-1/sqrt d): column jj of the factor below the diagonal, indexed by lo
+            asm volatile("" : "+v"(dcur), "+v"(a));                      // ... the next pivot and the column, then MFMA and stores
+            if constexpr (jj + 1 < NB) E = Tr<T>::mfma(a, a, E);
+            // column jj from the sixteen lanes of group K (zeros on and above the diagonal: the diagonal entry follows
+            // at the end of the panel, the strict upper triangle is never read), then -1/pivot, wave-uniform (every
+            // lane stores it: same address, same value) -- the column's flag: DS operations of one wave execute in order
+            lds_store_lanes<jj * DB_LD * (int)sizeof(T)>((unsigned)(size_t)(Lc + lo_), a, 0xFFFFull << (16 * K));
+            Lr[jj] = rinvn;
             asm volatile("" ::: "memory");
           });
-          if (bad) {
-            if (lane_ == 0) {
-              atomicCAS(info, 0, info_base + j0 + bad);
-              failed = 1;
-            }
-          } else {
-            // the factor of the diagonal block back into the block image (lower triangle), from the published columns
-            T *Dw = S + db_off(p, p) + lo_;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = 4 * hi_ + q;
-              if (lo_ >= c) Dw[c * DB_LD] = L.Lcol[c * NB + lo_];
+          // info (LAPACK: the first pivot that is not > 0, NaN included): exactly the pivots whose reciprocal is not
+          // finite (d <= 0 and NaN give NaN or Inf; +Inf gives -0, tiny d a large finite value).  Read back from the
+          // LDS (this wave's own stores, in order), sixteen at once -- nothing on the pivots' way.
+          int bad = 0;
+          {
+            const T rv = Lr[lo_];
+            const unsigned long long mb_ = __ballot(!(__builtin_fabs((double)rv) < __builtin_huge_val())) & 0xFFFFull;
+            if (mb_) bad = __builtin_ctzll(mb_) + 1;
+          }
+          // the sixteen pivots from the diagonal of E: lane (K(c), c) holds pivot c in register R(c)
+          {
+            const int rsel = (sizeof(T) == 8) ? (lo_ >> 2) : (lo_ & 3), ksel = (sizeof(T) == 8) ? (lo_ & 3) : (lo_ >> 2);
+            T dv = E[0];
+            dv = (rsel == 1) ? E[1] : dv;
+            dv = (rsel == 2) ? E[2] : dv;
+            dv = (rsel == 3) ? E[3] : dv;
+            const T d = -dv;
+            const bool mine = hi_ == ksel;
+            if (bad) {  // the first pivot that was not > 0 (NaN included)
+              if (lane_ == 0) {
+                atomicCAS(info, 0, info_base + j0 + bad);
+                failed = 1;
+              }
+            } else if (mine) {
+              T sq;
+              if constexpr (sizeof(T) == 8) {
+                const double r = __builtin_amdgcn_rsq((double)d);
+                const double dm = __builtin_fmin((double)d, 1.7976931348623157e308);
+                double g = dm * r, h = 0.5 * r;
+                double e = __builtin_fma(-h, g, 0.5);
+                g = __builtin_fma(g, e, g);
+                h = __builtin_fma(h, e, h);
+                e = __builtin_fma(-h, g, 0.5);
+                h = __builtin_fma(h, e, h);
+                g = __builtin_fma(g, e, g);
+                const double cc = __builtin_fma(-g, g, (double)d);
+                sq = (T)__builtin_fma(cc, h, g);
+                if (__double2hiint((double)d) == 0x7ff00000 && __double2loint((double)d) == 0)
+                  sq = (T)__builtin_huge_val();
+              } else {
+                T rinv;
+                sqrt_rsqrt(d, sq, rinv);
+              }
+              Lc[lo_ * (DB_LD + 1)] = sq;
             }
           }
         } else {
-          const int myrow = j0 + NB + 64 * (w - 1) + lane_;
-          const bool rows = (w < 3), rowok = rows && myrow < n;
+          // Followers: a lane of waves 1, 2 owns one row below the block (a lane beyond the last row repeats that
+          // row: same values to the same addresses), a lane of wave 3 one column of the inverse of the 16x16 factor
+          // (forward substitution on the identity; lanes 16-63 repeat lanes 0-15).  They take the factor about FOUR
+          // columns at a time: one poll of the last column's flag, then the columns (the rows still needed) and their
+          // reciprocals in one burst of LDS broadcast reads, then the right-looking updates of the own row.  Column
+          // by column (round 4) every column cost a round trip of ~150 cycles through the LDS, more than wave 0 now
+          // needs per pivot, and the followers ended a panel several columns behind.
+          const bool rows = (w < 3);
           const bool active = rows ? (j0 + NB + 64 * (w - 1) < n) : true;
           if (active) {
-            const unsigned flag_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&L.colready;
+            const unsigned flag_lds = (unsigned)(size_t)Lr + (sizeof(T) == 8 ? 4u : 0u);  // (the word with sign and exponent)
             const unsigned failed_lds = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&L.failed;
-            T a[NB];
-            const int rr = rowok ? myrow : n - 1;
+            const int myrow = j0 + NB + 64 * (w - 1) + lane_;
+            const int rr = (rows && myrow < n) ? myrow : n - 1;
             T *Rp = S + db_off(rr >> 4, p) + (rr & 15);
+            const unsigned long long okmask = __ballot(rows && myrow < n);
+            // (two copies of the unrolled sweep, one per kind of follower: with `rows` tested at run time every store
+            // of a column sat behind two scalar branches)
+            auto follow = [&](auto ROWS) {
+              constexpr bool rows_ = decltype(ROWS)::value;
+              T a[NB];
 #pragma unroll
-            for (int jj = 0; jj < NB; ++jj) a[jj] = rows ? Rp[jj * DB_LD] : ((lo_ == jj) ? T(1) : T(0));
-            const unsigned col_lds = (unsigned)(size_t)Lc, rinv_lds = (unsigned)(size_t)Lr;
+              for (int jj = 0; jj < NB; ++jj) a[jj] = rows_ ? Rp[jj * DB_LD] : ((lo_ == jj) ? T(1) : T(0));
+              T *Wp = Wd[p] + 16 * lo_;  // wave 3: column lo_ of the inverse, rows rotated (wd_idx)
+              // bursts of columns 0-3, 4-7, 8-11, 12-14 and, alone, 15: nothing of column 15 is needed but its
+              // reciprocal, so behind the last pivot a follower is ONE LDS round trip, one product and one store away
+              // from the barrier
+              static_for<0, 5>([&](auto Q) {
+                constexpr int q = decltype(Q)::value, c0 = 4 * q - (q == 4), nc = q < 3 ? 4 : (q == 3 ? 3 : 1);
+                lds_wait_flag(flag_lds + (c0 + nc - 1) * (unsigned)sizeof(T), failed_lds);
+                T col[4][NB], rn[4];
 #pragma unroll
-            for (int jj = 0; jj < NB; ++jj) {
-              ColFetch<T> cf;
-              cf.fetch(flag_lds, col_lds + jj * NB * (unsigned)sizeof(T), rinv_lds + jj * (unsigned)sizeof(T),
-                       fbase + jj + 1, failed_lds);
-              a[jj] *= cf.rinv;
+                for (int k = 0; k < nc; ++k) {
+                  rn[k] = Lr[c0 + k];
 #pragma unroll
-              for (int c = jj + 1; c < NB; ++c) a[c] -= a[jj] * cf.at(c);
-            }
-            if (rows) {
-              if (rowok) {
-#pragma unroll
-                for (int jj = 0; jj < NB; ++jj) Rp[jj * DB_LD] = a[jj];
-              }
-            } else if (lane_ < NB) {
-#pragma unroll
-              for (int jj = 0; jj < NB; ++jj) Wd[p][wd_idx(jj, lane_)] = a[jj];
-            }
+                  for (int c = c0 + k + 1; c < NB; ++c) col[k][c] = Lc[(c0 + k) * DB_LD + c];
+                }
+                static_for<0, nc>([&](auto KK) {
+                  constexpr int k = decltype(KK)::value, jj = c0 + k;
+                  a[jj] *= -rn[k];  // (wave 0 publishes MINUS the reciprocal)
+                  // (only the lanes that own a row / a column store)
+                  if constexpr (rows_) lds_store_lanes<jj * DB_LD * (int)sizeof(T)>((unsigned)(size_t)(lds_t *)Rp, a[jj], okmask);
+                  else lds_store_lanes<0>((unsigned)(size_t)(lds_t *)(Wp + ((jj + lo_) & 15)), a[jj], 0xFFFFull);
+                  // (each update pinned where it is written: left alone, the compiler sinks the updates of a column to
+                  // just before its scaling -- a left-looking sweep whose whole sum then sits on the way to the barrier,
+                  // with every fetched column kept in registers)
+                  static_for<jj + 1, NB>([&](auto C) {
+                    constexpr int c = decltype(C)::value;
+                    a[c] -= a[jj] * col[k][c];
+                    asm volatile("" : "+v"(a[c]));
+                  });
+                });
+              });
+            };
+            if (rows) follow(std::true_type{});
+            else follow(std::false_type{});
           }
         }
       }
@@ -1733,6 +1744,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
         }
         return;
       }
+      if (t < 16) L.Lrinv[t] = T(0);  // (the next panel's flags; its pollers start behind the barrier that ends phase B)
       if constexpr (FLOW) {
         // publish panel p: rows 16 p .. 127 of its 16 columns, on or below the diagonal; one wave instruction
         // stores one column (two consecutive rows per lane), so every 128-byte line is written whole by one store
@@ -2120,10 +2132,8 @@ __global__ __launch_bounds__(256, 2) void k_flow_factor(T *tile, int mb, int nbm
 #pragma unroll
       for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
     }
-    if (t == 0) {
-      L.failed = 0;
-      L.colready = 0;
-    }
+    if (t < 16) L.Lrinv[t] = T(0);
+    if (t == 0) L.failed = 0;
     __syncthreads();
   }
   bool live = true;

@@ -55,3 +55,42 @@ def kernel_resources(so_path: str) -> dict:
             rsrc1, = struct.unpack_from("<I", kd, 48)
             out[name[:-3]] = {"vgprs": ((rsrc1 & 0x3F) + 1) * 8, "lds": lds}
     return out
+
+
+def disassemble(so_path: str, arch: str = "gfx950") -> dict:
+    """{mangled kernel name: [instruction text, ...]} from llvm-objdump of the embedded code object."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+        f.write(device_elf(so_path, arch))
+        path = f.name
+    try:
+        text = subprocess.run([objdump, "-d", f"--mcpu={arch}", "--no-show-raw-insn", path], check=True, capture_output=True, text=True).stdout
+    finally:
+        os.unlink(path)
+    out, cur = {}, None
+    for ln in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if cur is not None and ln.startswith("\t"):
+            ins = ln.split("//")[0].strip()
+            if ins:
+                cur.append(ins)
+    return out
+
+
+def vgprs_of(ins: str) -> set:
+    """VGPR numbers an instruction names (v7, v[4:5])."""
+    import re
+
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", ins):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", ins))
+    return regs
