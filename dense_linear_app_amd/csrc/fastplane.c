@@ -217,6 +217,59 @@ fail:
   return NULL;
 }
 
+/* ---- task_creations(cls, payload_ids, output_ids, items) -> [TaskCreation] -------------------------------------
+ * The client's per-task TaskCreation{payload_id, expected_output_keys = [output], data_dependencies = sorted unique
+ * ids} (C2:480-492) for a whole submission; items[i] = (payload text, [dependency ids]). */
+static PyObject *task_creations(PyObject *self, PyObject *args) {
+  PyObject *cls, *pids, *outs, *items;
+  if (!PyArg_ParseTuple(args, "OO!O!O!", &cls, &PyList_Type, &pids, &PyList_Type, &outs, &PyList_Type, &items)) return NULL;
+  const Py_ssize_t n = PyList_GET_SIZE(items);
+  if (PyList_GET_SIZE(pids) != n || PyList_GET_SIZE(outs) != n) {
+    PyErr_SetString(PyExc_ValueError, "task_creations: lists of different lengths");
+    return NULL;
+  }
+  PyObject *res = PyList_New(n);
+  if (!res) return NULL;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *it = PyList_GET_ITEM(items, i);
+    PyObject *src = (PyTuple_Check(it) && PyTuple_GET_SIZE(it) >= 2) ? PyTuple_GET_ITEM(it, 1) : NULL;
+    if (!src || !PyList_Check(src)) {
+      PyErr_SetString(PyExc_TypeError, "task_creations: items must be (payload, [dependency ids])");
+      goto fail;
+    }
+    PyObject *deps = PyList_GetSlice(src, 0, PyList_GET_SIZE(src));
+    if (!deps || PyList_Sort(deps)) {
+      Py_XDECREF(deps);
+      goto fail;
+    }
+    for (Py_ssize_t q = PyList_GET_SIZE(deps) - 1; q > 0; --q) {  /* unique (sorted: equal ids are neighbours) */
+      const int eq = PyObject_RichCompareBool(PyList_GET_ITEM(deps, q), PyList_GET_ITEM(deps, q - 1), Py_EQ);
+      if (eq < 0 || (eq && PyList_SetSlice(deps, q, q + 1, NULL))) {
+        Py_DECREF(deps);
+        goto fail;
+      }
+    }
+    PyObject *keys = PyList_New(1), *tc = new_instance(cls);
+    int bad = !keys || !tc;
+    if (!bad) {
+      Py_INCREF(PyList_GET_ITEM(outs, i));
+      PyList_SET_ITEM(keys, 0, PyList_GET_ITEM(outs, i));
+      bad = set(tc, s_payload_id, PyList_GET_ITEM(pids, i)) || set(tc, s_expected_output_keys, keys) || set(tc, s_data_dependencies, deps);
+    }
+    Py_XDECREF(keys);
+    Py_DECREF(deps);
+    if (bad) {
+      Py_XDECREF(tc);
+      goto fail;
+    }
+    PyList_SET_ITEM(res, i, tc);
+  }
+  return res;
+fail:
+  Py_DECREF(res);
+  return NULL;
+}
+
 /* 1 ready, 0 not, -1 error: the payload and every data dependency of the task are completed (ControlPlane._ready) */
 static int task_ready(PyObject *t, PyObject *results) {
   PyObject *pid = PyObject_GetAttr(t, s_payload_id), *deps = PyObject_GetAttr(t, s_data_dependencies);
@@ -579,6 +632,7 @@ static PyMethodDef methods[] = {
     {"resolve_batch", resolve_batch, METH_VARARGS, "resolve_batch(tasks, results, buf, ops, Bs, id_off, id_len, blob_cls, async_potrf) -> (groups, fallback)"},
     {"complete_batch", complete_batch, METH_VARARGS, "complete_batch(tasks, idxs, results, blob_cls, parent, base, tb, epoch, out, ok_status) -> [output ids]"},
     {"book_batch", book_batch, METH_VARARGS, "book_batch(tasks, statuses, results, executed, ok_status) -> [slow indices]"},
+    {"task_creations", task_creations, METH_VARARGS, "task_creations(cls, payload_ids, output_ids, items) -> [TaskCreation]"},
     {"tasks_of", tasks_of, METH_O, "tasks_of(handlers) -> [handler._task]"},
     {NULL, NULL, 0, NULL}};
 

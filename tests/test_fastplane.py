@@ -211,3 +211,19 @@ def test_plane_rules_hold_in_both(fast, monkeypatch):
         rc.upload_results_data(sid, {ids["payload/0"]: "y"})
     t = tcl.submit_tasks(sid, [ak.TaskCreation(ids["payload/0"], [ids["a"]], [ids["b"]])])
     assert plane._tasks[t[0]].status == "pending" and plane._pending == t  # b has no data yet
+
+
+def test_task_creations_in_c_are_the_python_ones():
+    """client.submit_batch: TaskCreation{payload, [output], sorted unique dependencies} (C2:480-492) built in C."""
+    if ak.FAST is None:
+        pytest.skip("_fastplane not built")
+    items = [("p0", ["b", "a", "c"]), ("p1", ["x"]), ("p2", ["k", "k", "j"]), ("p3", ["z", "y"]), ("p4", [])]
+    pids, outs = [f"pid{i}" for i in range(5)], [f"out{i}" for i in range(5)]
+    got = ak.FAST.task_creations(ak.TaskCreation, pids, outs, items)
+    want = [ak.TaskCreation(p, [o], sorted(set(it[1]))) for p, o, it in zip(pids, outs, items)]
+    assert got == want and all(type(g) is ak.TaskCreation for g in got)
+    assert items[0][1] == ["b", "a", "c"]  # (the caller's lists are not touched)
+    with pytest.raises(ValueError):
+        ak.FAST.task_creations(ak.TaskCreation, pids[:2], outs, items)
+    with pytest.raises(TypeError):
+        ak.FAST.task_creations(ak.TaskCreation, pids[:1], outs[:1], [("p", "not a list")])
