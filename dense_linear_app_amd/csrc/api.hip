@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -104,6 +105,30 @@ struct TaskExec {
   long long fused_panels = 0;
 };
 TaskExec tx;
+// The executor's ORDERING checked without a GPU (chol_debug_task_record / chol_debug_task_check, tests/
+// test_schedule_check.py): in recording mode the same code runs -- dependency tracking, the pending-POTRF / pipelined
+// panel logic, ring slices, marks -- but every HIP call is skipped and every batch is logged with the tiles it reads
+// and writes, its stream and sequence number, the event waits issued for it and what the host knew to be complete.
+// The check: any two batches that touch the same tile, one of them writing it, must be ordered by stream order, by a
+// chain of event waits, or by a host-side wait.  `mutate` >= 0 drops that one event wait (the checker's self-test).
+struct TxRecord {
+  struct Op {
+    int stream;
+    unsigned long long seq, base[2];  // base: the batches of each stream the host had waited for when this one was issued
+    std::vector<const void *> rd, wr;
+    std::vector<std::pair<int, unsigned long long>> waits;  // (producer stream, sequence number) of each event wait
+  };
+  bool on = false;
+  int mutate = -1;
+  long long nwaits = 0;
+  std::vector<Op> ops;
+  std::vector<const void *> rd;                                  // reads followed since the last commit
+  std::vector<std::pair<int, unsigned long long>> pending[2];   // waits issued on a stream since its last batch
+} tx_rec;
+#define TXHIP(call)                 \
+  do {                              \
+    if (!tx_rec.on) HIPCHECK(call); \
+  } while (0)
 int tx_quiesce();
 double g_task_yield_factor = 6.0;  // CHOLMI_TASK_YIELD_FACTOR
 Ctx g;
@@ -183,6 +208,13 @@ void forget_winv(const void *ptr) {
 // ---- the task executor (TaskExec above) ------------------------------------------------------------------------
 int tx_init() {
   if (tx.ready) return 0;
+  if (tx_rec.on) {  // (recording: no streams, no events; the pointer-list ring is plain host memory)
+    tx.h_ring = static_cast<char *>(malloc(tx.ring_bytes));
+    tx.d_ring = tx.h_ring;
+    if (!tx.h_ring) return fail(CHOL_ERR_HIP, "task recorder: out of memory");
+    tx.ready = true;
+    return 0;
+  }
   tx.st[TaskExec::CHAIN] = g.r.st[ST_PANEL];
   tx.st[TaskExec::BULK] = g.r.st[ST_MAIN];
   for (int s = 0; s < 2; ++s)
@@ -197,6 +229,11 @@ int tx_init() {
 }
 void tx_destroy() {
   if (!tx.ready) return;
+  if (tx_rec.on) {
+    free(tx.h_ring);
+    tx = TaskExec();
+    return;
+  }
   for (int s = 0; s < 2; ++s)
     for (int i = 0; i < TaskExec::EVPOOL; ++i)
       if (tx.ev[s][i]) (void)hipEventDestroy(tx.ev[s][i]);
@@ -212,8 +249,8 @@ int tx_flush_pending();
 int tx_quiesce() {
   if (!tx.ready || !tx.dirty) return 0;
   if (int rc = tx_flush_pending()) return rc;
-  HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));
-  HIPCHECK(hipStreamSynchronize(tx.st[TaskExec::BULK]));
+  TXHIP(hipStreamSynchronize(tx.st[TaskExec::CHAIN]));
+  TXHIP(hipStreamSynchronize(tx.st[TaskExec::BULK]));
   for (int s = 0; s < 2; ++s) {
     tx.done[s] = tx.seq[s];
     tx.waited[s][0] = tx.waited[s][1] = 0;
@@ -229,7 +266,7 @@ int tx_quiesce() {
 int tx_wait_host(int stream, unsigned long long seq) {
   if (tx.done[stream] >= seq) return 0;
   const int slot = (int)(seq % TaskExec::EVPOOL);
-  HIPCHECK(hipEventSynchronize(tx.ev[stream][slot]));
+  TXHIP(hipEventSynchronize(tx.ev[stream][slot]));
   tx.done[stream] = std::max(tx.done[stream], tx.ev_seq[stream][slot]);
   return 0;
 }
@@ -256,6 +293,10 @@ int tx_take(size_t bytes, size_t *off) {
 int tx_follow(int X, const void *const *const *lists, int nl, int n) {
   const int Y = 1 - X;
   unsigned long long need = 0;
+  if (tx_rec.on)
+    for (int l = 0; l < nl; ++l)
+      for (int t = 0; lists[l] && t < n; ++t)
+        if (lists[l][t]) tx_rec.rd.push_back(lists[l][t]);
   if (!tx.prod.empty())
     for (int l = 0; l < nl; ++l) {
       if (!lists[l]) continue;
@@ -268,7 +309,13 @@ int tx_follow(int X, const void *const *const *lists, int nl, int n) {
     }
   if (need > tx.waited[X][Y]) {
     if (tx.done[Y] < need) {
-      HIPCHECK(hipStreamWaitEvent(tx.st[X], tx.ev[Y][need % TaskExec::EVPOOL], 0));
+      // (the pool's event of that slot stands for batch ev_seq >= need of stream Y: a later batch if the slot has been
+      // recorded again since -- a longer wait, never a shorter one)
+      if (tx_rec.on) {
+        if (tx_rec.nwaits++ != tx_rec.mutate) tx_rec.pending[X].push_back({Y, tx.ev_seq[Y][need % TaskExec::EVPOOL]});
+      } else {
+        HIPCHECK(hipStreamWaitEvent(tx.st[X], tx.ev[Y][need % TaskExec::EVPOOL], 0));
+      }
       ++tx.cross_waits;
     }
     tx.waited[X][Y] = need;
@@ -279,8 +326,16 @@ int tx_follow(int X, const void *const *const *lists, int nl, int n) {
 int tx_commit(int X, void *const *outs, int n, size_t slice_b, size_t slice_e) {
   const unsigned long long seq = ++tx.seq[X];
   const int slot = (int)(seq % TaskExec::EVPOOL);
-  HIPCHECK(hipEventRecord(tx.ev[X][slot], tx.st[X]));
+  TXHIP(hipEventRecord(tx.ev[X][slot], tx.st[X]));
   tx.ev_seq[X][slot] = seq;
+  if (tx_rec.on) {
+    TxRecord::Op op;
+    op.stream = X, op.seq = seq, op.base[0] = tx.done[0], op.base[1] = tx.done[1];
+    op.rd.swap(tx_rec.rd);
+    op.wr.assign(outs, outs + n);
+    op.waits.swap(tx_rec.pending[X]);
+    tx_rec.ops.push_back(std::move(op));
+  }
   for (int t = 0; t < n; ++t) tx.prod[outs[t]] = TaskExec::Prod{X, seq};
   if (slice_e > slice_b) tx.slices.push_back(TaskExec::Slice{slice_b, slice_e, X, seq});
   ++tx.batches[X];
@@ -1140,6 +1195,10 @@ int chol_desc_set_version(chol_desc_t *d, unsigned long long version) {
 }
 
 int chol_sync(void) {
+  if (tx_rec.on) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tx_quiesce();
+  }
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "chol_sync before chol_init");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   HIPCHECK(hipStreamSynchronize(g.r.st[ST_MAIN]));
@@ -1157,13 +1216,13 @@ static int flush_pending_t() {
   const TaskExec::Pending p = tx.pend;
   tx.pend.on = false;
   hipStream_t s = tx.st[TaskExec::CHAIN];
-  HIPCHECK(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), s));
-  HIPCHECK(hipMemcpyAsync(p.a_out, p.a_in, (size_t)p.mb * p.mb * sizeof(T), hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
+  TXHIP(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), s));
+  TXHIP(hipMemcpyAsync(p.a_out, p.a_in, (size_t)p.mb * p.mb * sizeof(T), hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
   T *wset = reinterpret_cast<T *>(tx_winv_set());
-  launch_potrf_tile<T>(s, reinterpret_cast<T *>(p.a_out), p.mb, wset, g.d_binfo + p.slot, 0, tile_sems());
+  if (!tx_rec.on) launch_potrf_tile<T>(s, reinterpret_cast<T *>(p.a_out), p.mb, wset, g.d_binfo + p.slot, 0, tile_sems());
   forget_winv(p.a_out);
   tx_remember_winv(p.a_out, p.version, p.mb, p.dtype, wset);
-  HIPCHECK(hipGetLastError());
+  TXHIP(hipGetLastError());
   void *outs[1] = {p.a_out};
   return tx_commit(TaskExec::CHAIN, outs, 1, 0, 0);
 }
@@ -1194,28 +1253,34 @@ static int panel_fused_impl(int dtype, int mb, int n, const void *const *c_in, v
   const void *const *ins[1] = {c_in};
   rc = tx_follow(X, ins, 1, n);  // (the POTRF's own input was followed when it was stashed)
   if (rc) return rc;
+  // (the TRSM stream inside this issue is not the recorder's business: it starts behind an event of the chain stream
+  // and is joined back into it, so the tracker -- and the recorder -- see ONE batch of the chain stream; the launches
+  // inside are launch_panel_pipelined's, the whole-matrix walker's, whose ordering csrc/sched_check.hip covers)
   hipEvent_t ev_pre = tx.pev[34], ev_join = tx.pev[35];
-  HIPCHECK(hipEventRecord(ev_pre, sp));
-  HIPCHECK(hipStreamWaitEvent(st, ev_pre, 0));
+  TXHIP(hipEventRecord(ev_pre, sp));
+  TXHIP(hipStreamWaitEvent(st, ev_pre, 0));
   // the private copies: the diagonal tile on the chain stream, the panel tiles on the TRSM stream (beside the first steps)
-  HIPCHECK(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), sp));
-  HIPCHECK(hipMemcpyAsync(p.a_out, p.a_in, tb, hipMemcpyDeviceToDevice, sp));
-  HIPCHECK(hipMemcpyAsync(dl, hl, 2 * lb, hipMemcpyHostToDevice, st));
-  launch_copy_ptrs(st, (const void *const *)dl, (void *const *)(dl + lb), n, (long)tb);
+  TXHIP(hipMemsetAsync(g.d_binfo + p.slot, 0, sizeof(int), sp));
+  TXHIP(hipMemcpyAsync(p.a_out, p.a_in, tb, hipMemcpyDeviceToDevice, sp));
+  TXHIP(hipMemcpyAsync(dl, hl, 2 * lb, hipMemcpyHostToDevice, st));
   T *wset = reinterpret_cast<T *>(tx_winv_set());
-  launch_panel_pipelined<T>(sp, st, tx.pev, reinterpret_cast<T *>(p.a_out), mb, wset, g.d_binfo + p.slot, 0,
-                            reinterpret_cast<T *>(c_out[0]), (long)mb * mb, n, nullptr, nullptr, nullptr, 0, tile_sems());
+  if (!tx_rec.on) {
+    launch_copy_ptrs(st, (const void *const *)dl, (void *const *)(dl + lb), n, (long)tb);
+    launch_panel_pipelined<T>(sp, st, tx.pev, reinterpret_cast<T *>(p.a_out), mb, wset, g.d_binfo + p.slot, 0,
+                              reinterpret_cast<T *>(c_out[0]), (long)mb * mb, n, nullptr, nullptr, nullptr, 0, tile_sems());
+  }
   (void)nbm;
-  HIPCHECK(hipEventRecord(ev_join, st));
-  HIPCHECK(hipStreamWaitEvent(sp, ev_join, 0));
+  TXHIP(hipEventRecord(ev_join, st));
+  TXHIP(hipStreamWaitEvent(sp, ev_join, 0));
   forget_winv(p.a_out);
   for (int t = 0; t < n; ++t) forget_winv(c_out[t]);
   tx_remember_winv(p.a_out, p.version, mb, dtype, wset);
-  HIPCHECK(hipGetLastError());
+  TXHIP(hipGetLastError());
   ++tx.fused_panels;
   void *outs1[1] = {p.a_out};
   rc = tx_commit(X, outs1, 1, 0, 0);
   if (rc) return rc;
+  if (tx_rec.on) tx_rec.rd.push_back(p.a_out);  // (the solves read the factor just written: same stream)
   return tx_commit(X, c_out, n, off, off + 2 * lb);
 }
 
@@ -1250,7 +1315,7 @@ static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *
   const void *const *ins[3] = {c_in, a, op == CHOL_BATCH_SYRK ? nullptr : b};
   rc = tx_follow(X, ins, 3, n);
   if (rc) return rc;
-  HIPCHECK(hipMemcpyAsync(dl, hl, 4 * lb, hipMemcpyHostToDevice, s));
+  TXHIP(hipMemcpyAsync(dl, hl, 4 * lb, hipMemcpyHostToDevice, s));
   const void *const *d_cin = (const void *const *)dl, *const *d_a = (const void *const *)(dl + lb),
                     *const *d_b = (const void *const *)(dl + 2 * lb);
   void *const *d_out = (void *const *)(dl + 3 * lb);
@@ -1265,10 +1330,11 @@ static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *
     // the walker's pipelined one -- and beside an update that does not yield its diagonal-block steps take 230-370 us
     // instead of 50: profiles/r05_worker_path_trace_N16384_B512.txt)
     const bool yield = X == TaskExec::BULK && g.r.probe_tflops[f] > 0 && n * t_tile < g_task_yield_factor * t_panel;
-    launch_update_ptrs<T>(s, (const T *const *)d_cin, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, yield);
+    if (!tx_rec.on)
+      launch_update_ptrs<T>(s, (const T *const *)d_cin, (const T *const *)d_a, (const T *const *)d_b, (T *const *)d_out, n, mb, yield);
   } else {
     // TRSM: private copies, then runs of consecutive tasks with the same L and outputs laid out back to back as panels
-    launch_copy_ptrs(s, d_cin, d_out, n, (long)tb);
+    if (!tx_rec.on) launch_copy_ptrs(s, d_cin, d_out, n, (long)tb);
     int t0 = 0;
     while (t0 < n) {
       int t1 = t0 + 1;
@@ -1281,15 +1347,15 @@ static int tile_batch_impl(int op, int dtype, int mb, int n, const void *const *
       if (!w) w = reinterpret_cast<const T *>(cached_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype));
       if (!w) {
         T *wn = reinterpret_cast<T *>(tx_winv_set());
-        launch_invert_diag<T>(s, L, mb, wn);
+        if (!tx_rec.on) launch_invert_diag<T>(s, L, mb, wn);
         tx_remember_winv(a[t0], a_versions ? a_versions[t0] : 0, mb, dtype, wn);
         w = wn;
       }
-      launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[t0]), (long)mb * mb, t1 - t0, L, w, mb, T(1));
+      if (!tx_rec.on) launch_trsm_panel<T>(s, reinterpret_cast<T *>(c_out[t0]), (long)mb * mb, t1 - t0, L, w, mb, T(1));
       t0 = t1;
     }
   }
-  HIPCHECK(hipGetLastError());
+  TXHIP(hipGetLastError());
   return tx_commit(X, c_out, n, off, off + 4 * lb);
 }
 
@@ -1302,7 +1368,7 @@ static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, v
   const int X = TaskExec::CHAIN;
   hipStream_t s = tx.st[X];
   const size_t tb = (size_t)mb * mb * sizeof(T);
-  if (!g.d_binfo) {
+  if (!g.d_binfo && !tx_rec.on) {
     HIPCHECK(hipMalloc(&g.d_binfo, BINFO_SLOTS * sizeof(int)));
     HIPCHECK(hipMemset(g.d_binfo, 0, BINFO_SLOTS * sizeof(int)));
   }
@@ -1324,14 +1390,14 @@ static int potrf_batch_impl(int dtype, int mb, int n, const void *const *a_in, v
   for (int t = 0; t < n; ++t) {
     const int slot = (int)(g.binfo_next++ % BINFO_SLOTS);
     slots[t] = slot;
-    HIPCHECK(hipMemsetAsync(g.d_binfo + slot, 0, sizeof(int), s));
-    HIPCHECK(hipMemcpyAsync(a_out[t], a_in[t], tb, hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
+    TXHIP(hipMemsetAsync(g.d_binfo + slot, 0, sizeof(int), s));
+    TXHIP(hipMemcpyAsync(a_out[t], a_in[t], tb, hipMemcpyDeviceToDevice, s));  // the private copy (W2:212-213)
     T *wset = reinterpret_cast<T *>(tx_winv_set());
-    launch_potrf_tile<T>(s, reinterpret_cast<T *>(a_out[t]), mb, wset, g.d_binfo + slot, 0, tile_sems());
+    if (!tx_rec.on) launch_potrf_tile<T>(s, reinterpret_cast<T *>(a_out[t]), mb, wset, g.d_binfo + slot, 0, tile_sems());
     forget_winv(a_out[t]);
     tx_remember_winv(a_out[t], versions ? versions[t] : 0, mb, dtype, wset);
   }
-  HIPCHECK(hipGetLastError());
+  TXHIP(hipGetLastError());
   return tx_commit(X, a_out, n, 0, 0);
 }
 
@@ -1339,7 +1405,7 @@ extern "C" {
 
 int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *const *a_out,
                      const unsigned long long *versions, int *slots, int flags) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_batch before chol_init");
+  if (!g.inited && !tx_rec.on) return fail(CHOL_ERR_NOT_INITIALIZED, "potrf_batch before chol_init");
   if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-1, "potrf_batch: dtype");
   if (mb <= 0 || mb % MACRO || mb > 4096) return fail(CHOL_ERR_NOT_SUPPORTED, "potrf_batch: tile edge must be a multiple of 128, at most 4096");
   if (n < 0 || n > BINFO_SLOTS / 2) return fail(-3, "potrf_batch: n");
@@ -1355,6 +1421,11 @@ int chol_potrf_batch(int dtype, int mb, int n, const void *const *a_in, void *co
 }
 
 int chol_batch_info(int slot, int *info) {
+  if (tx_rec.on) {  // (recording: nothing ran)
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (info) *info = 0;
+    return tx_flush_pending();
+  }
   if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "batch_info before chol_init");
   if (!info || slot < 0 || slot >= BINFO_SLOTS || !g.d_binfo) return fail(-1, "batch_info: slot");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1366,7 +1437,7 @@ int chol_batch_info(int slot, int *info) {
 
 int chol_tile_batch(int op, int dtype, int mb, int n, const void *const *c_in, const void *const *a,
                     const void *const *b, void *const *c_out, const unsigned long long *a_versions, int flags) {
-  if (!g.inited) return fail(CHOL_ERR_NOT_INITIALIZED, "tile_batch before chol_init");
+  if (!g.inited && !tx_rec.on) return fail(CHOL_ERR_NOT_INITIALIZED, "tile_batch before chol_init");
   if (op != CHOL_BATCH_TRSM && op != CHOL_BATCH_SYRK && op != CHOL_BATCH_GEMM && op != CHOL_BATCH_UPDATE) return fail(-1, "tile_batch: op");
   if (dtype != CHOL_REAL_DOUBLE && dtype != CHOL_REAL_FLOAT) return fail(-2, "tile_batch: dtype");
   if (mb <= 0 || mb % MACRO || mb > 4096) return fail(CHOL_ERR_NOT_SUPPORTED, "tile_batch: tile edge must be a multiple of 128, at most 4096");
@@ -1412,6 +1483,92 @@ int chol_batch_stats(long long *out4) {
   if (!out4) return fail(-1, "batch_stats: NULL");
   out4[0] = tx.batches[TaskExec::CHAIN], out4[1] = tx.batches[TaskExec::BULK], out4[2] = tx.cross_waits, out4[3] = (long long)tx.prod.size();
   if (getenv("CHOLMI_VERBOSE")) fprintf(stderr, "[cholmi] task executor: %lld panels issued pipelined (POTRF + its TRSM batch)\n", tx.fused_panels);
+  return 0;
+}
+
+// ---- the executor's ordering, checked without a GPU (TxRecord above)
+int chol_debug_task_record(int on, int mutate) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (on) {
+    if (g.inited) return fail(CHOL_ERR_NOT_SUPPORTED, "task recorder: only before chol_init (it replaces the executor's streams)");
+    tx_destroy();
+    tx_rec = TxRecord();
+    tx_rec.on = true;
+    tx_rec.mutate = mutate;
+    tx_wc = TxWinv();
+    return 0;
+  }
+  if (tx_rec.on) {
+    tx_destroy();
+    tx_rec.on = false;
+  }
+  return 0;
+}
+
+// out5 = {batches recorded, event waits recorded, conflicting pairs examined, pairs not ordered, host-ordered pairs};
+// the first unordered pair is described in chol_last_error()
+int chol_debug_task_check(long long *out5) {
+  if (!out5) return fail(-1, "task_check: NULL");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  const auto &ops = tx_rec.ops;
+  const size_t n = ops.size();
+  // what of each stream precedes an op: its own stream up to seq - 1, every (stream, seq) it waited for, and what those
+  // preceded in turn (clock[i][s] = newest batch of stream s known to be complete before op i starts)
+  std::vector<std::array<unsigned long long, 2>> clock(n);
+  std::unordered_map<unsigned long long, size_t> index[2];
+  long long nwaits = 0, pairs = 0, bad = 0, hosted = 0;
+  char first[256] = "";
+  std::unordered_map<const void *, size_t> writer;
+  std::unordered_map<const void *, std::vector<size_t>> readers;
+  for (size_t i = 0; i < n; ++i) {
+    const auto &op = ops[i];
+    std::array<unsigned long long, 2> c = {op.base[0], op.base[1]};
+    auto absorb = [&](int s, unsigned long long q) {
+      if (q == 0) return;
+      c[s] = std::max(c[s], q);
+      auto it = index[s].find(q);
+      if (it != index[s].end())
+        for (int z = 0; z < 2; ++z) c[z] = std::max(c[z], clock[it->second][z]);
+    };
+    absorb(op.stream, op.seq - 1);
+    for (const auto &w : op.waits) absorb(w.first, w.second), ++nwaits;
+    clock[i] = c;
+    index[op.stream][op.seq] = i;
+    auto ordered = [&](size_t j) {  // op j (issued earlier) completes before op i starts
+      const auto &o = ops[j];
+      if (o.stream == op.stream) return true;
+      if (op.base[o.stream] >= o.seq) {
+        ++hosted;
+        return true;
+      }
+      return c[o.stream] >= o.seq;
+    };
+    auto examine = [&](size_t j, const void *p, const char *kind) {
+      if (j == i) return;
+      ++pairs;
+      if (!ordered(j)) {
+        if (!bad)
+          snprintf(first, sizeof first, "task executor: batch %llu of stream %d %s tile %p of batch %llu of stream %d without being ordered behind it",
+                   op.seq, op.stream, kind, p, ops[j].seq, ops[j].stream);
+        ++bad;
+      }
+    };
+    for (const void *p : op.rd) {
+      auto it = writer.find(p);
+      if (it != writer.end()) examine(it->second, p, "reads");
+    }
+    for (const void *p : op.wr) {
+      auto it = writer.find(p);
+      if (it != writer.end()) examine(it->second, p, "overwrites");
+      auto rt = readers.find(p);
+      if (rt != readers.end())
+        for (size_t j : rt->second) examine(j, p, "overwrites what is read by");
+    }
+    for (const void *p : op.rd) readers[p].push_back(i);
+    for (const void *p : op.wr) writer[p] = i, readers.erase(p);
+  }
+  out5[0] = (long long)n, out5[1] = nwaits, out5[2] = pairs, out5[3] = bad, out5[4] = hosted;
+  if (bad) set_error(first);
   return 0;
 }
 

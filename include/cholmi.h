@@ -284,6 +284,17 @@ int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int
 int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
                                    char *report, int cap);
 
+/* The ordering of the task executor (chol_tile_batch / chol_potrf_batch) checked WITHOUT a GPU.
+ * chol_debug_task_record(1, mutate) -- only before chol_init -- puts the executor into recording mode: the grouped-launch
+ * entry points (and chol_batch_mark / _wait / _info, chol_sync) run their real dependency tracking on whatever pointer
+ * values the caller passes (they are never dereferenced), skip every HIP call and log each batch with the tiles it reads
+ * and writes, its stream, its event waits and what the host knew to be complete.  mutate >= 0 drops that one event wait
+ * (self-test).  chol_debug_task_check(out5) then examines every pair of batches that touch the same tile, one of them
+ * writing: out5 = {batches, event waits, pairs examined, pairs NOT ordered, pairs ordered by a host-side wait};
+ * chol_last_error() describes the first unordered pair.  chol_debug_task_record(0, -1) leaves the mode. */
+int chol_debug_task_record(int on, int mutate);
+int chol_debug_task_check(long long *out5);
+
 /* What the walker's regime switches (pairs / halves / counter-linked chain / CU hand-over) are measured in,
  * taken once at chol_init (or from CHOLMI_CALIB="tf64,us64,tf32,us32"): out8[0..3] = fp64 MFMA probe
  * [TFLOP/s], fp64 128 x 128 diagonal-block step alone [us], the same for fp32; out8[4..7] = the derived

@@ -147,3 +147,73 @@ def test_a_flow_wave_behind_a_paired_wave_is_ordered_by_its_join_event(monkeypat
             joins.append((i, n, rep))
     assert joins, "no flow wave joined its stream by an event in this schedule"
     assert all(n > 0 and "row slabs" in rep for _, n, rep in joins), joins
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The TASK executor (chol_tile_batch / chol_potrf_batch: two streams, per-tile event ordering, the pending POTRF that
+# goes out pipelined with its panel's TRSM batch) -- checked through the product's own client, control plane and worker:
+# only the tile allocations are stand-ins (addresses that are never dereferenced), the library runs in recording mode.
+def _task_path_record(N, B, mutate=-1, retire_bytes=None, monkeypatch=None):
+    import ctypes as C
+
+    import numpy as np
+
+    from dense_linear_app_amd import armonik as ak, client
+    from dense_linear_app_amd._lib import lib
+    from dense_linear_app_amd.worker import DagCholeskyWorker, HipTileBackend
+
+    class _Fake:
+        def __init__(self, nbytes, ptr): self.n, self.p = nbytes, ptr
+        def numel(self): return self.n
+        def element_size(self): return 1
+        def data_ptr(self): return self.p
+
+    class Backend(HipTileBackend):  # (tile_batch / potrf_batch are the product's: they call the library)
+        nxt = 1 << 30
+        def sync_inputs(self): pass
+        def batch_alloc(self, m, B):
+            Backend.nxt += m * B * B * 8
+            return _Fake(m * B * B * 8, Backend.nxt), Backend.nxt
+
+    def fake_from_bytes(cls, data):
+        Backend.nxt += len(data)
+        return cls(_Fake(len(data), Backend.nxt))
+
+    L = lib()
+    assert L.chol_debug_task_record(1, mutate) == 0
+    try:
+        monkeypatch.setattr(ak.DeviceBlob, "from_bytes", classmethod(fake_from_bytes))
+        if retire_bytes is not None:
+            monkeypatch.setenv("CHOLESKY_RETIRE_BYTES", str(retire_bytes))
+        plane = ak.ControlPlane(device_results=True, batch_ready=True)
+        w = DagCholeskyWorker(backend=Backend())
+        r = client.run_cholesky_dag(N, B, plane=plane, worker=w, A=np.zeros((N, N), order="F"), device_results=True, batched=True)
+        out = (C.c_longlong * 5)()
+        assert L.chol_debug_task_check(out) == 0
+        return r, list(out), L.chol_last_error().decode()
+    finally:
+        L.chol_debug_task_record(0, -1)
+
+
+@pytest.mark.parametrize("N,B", [(1024, 128), (2560, 256), (4096, 512), (6144, 512), (24 * 128, 128)])
+def test_the_task_executor_orders_every_conflicting_pair_of_batches(N, B, monkeypatch):
+    r, (batches, waits, pairs, unordered, hosted), msg = _task_path_record(N, B, monkeypatch=monkeypatch)
+    nb = N // B
+    assert sum(r.task_counts.values()) == nb + nb * (nb - 1) // 2 + nb * (nb - 1) // 2 + nb * (nb - 1) * (nb - 2) // 6
+    # POTRF + its TRSM batch go out as one pipelined issue that the tracker books as two batches of the chain stream
+    assert batches >= 3 * (nb - 1) and waits > 0 and pairs > batches
+    assert unordered == 0, msg
+
+
+def test_the_task_executor_check_holds_with_versions_retired_behind_marks(monkeypatch):
+    """Superseded tile versions released behind chol_batch_wait (client: CHOLESKY_RETIRE_BYTES): the host-side waits are
+    part of the order (their addresses are not reused by the stand-in allocator, so this exercises marks and waits)."""
+    r, (batches, waits, pairs, unordered, hosted), msg = _task_path_record(4096, 256, retire_bytes=8 << 20, monkeypatch=monkeypatch)
+    assert unordered == 0, msg
+
+
+@pytest.mark.parametrize("drop", [0, 1, 2, 5, 9])
+def test_the_task_executor_check_sees_a_missing_event_wait(drop, monkeypatch):
+    """Self-test by mutation: with ONE cross-stream event wait dropped the checker must report an unordered pair."""
+    _, (batches, waits, pairs, unordered, hosted), msg = _task_path_record(4096, 512, mutate=drop, monkeypatch=monkeypatch)
+    assert unordered > 0 and "without being ordered" in msg, (drop, waits, msg)
