@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         "chol_last_potrf_regimes": ([C.POINTER(i), C.POINTER(i)], i),
         "chol_debug_schedule_check": ([i, i, d, d, i, C.c_char_p, i], i),
         "chol_debug_schedule_check_grid": ([i, i, i, i, i, d, d, i, C.c_char_p, i], i),
+        "chol_debug_comm_trace": ([i, i, i, i, i, d, d, C.c_char_p, i], i),
         "chol_debug_task_record": ([i, i], i),
         "chol_debug_task_check": ([C.POINTER(C.c_longlong)], i),
         "chol_last_potrf_stats": ([C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(d)], i),

@@ -17,6 +17,7 @@
 #include <bitset>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <set>
 #include <string>
@@ -37,6 +38,9 @@ struct TraceOps {
     std::string name;
     std::vector<std::pair<long, bool>> acc;  // (slot, written): tile-sized slots of a made-up address space, see slot_of
     std::vector<int> deps;
+    int ch = -1, peer = -1, group = -1;  // a transport call: channel, peer, the group (per channel) it belongs to
+    bool is_send = false;
+    size_t bytes = 0;
   };
   std::vector<Op> ops;
   int last_on[ST_COUNT];
@@ -241,22 +245,51 @@ struct TraceOps {
     add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
     return 0;
   }
-  // the transport of a grid: a send reads, a receive writes, on the stream it is issued on
-  static int t_begin(void *) { return 0; }
+  // the transport of a grid: a send reads, a receive writes, on the stream it is issued on; each call also remembers its
+  // channel, peer, size and group (chol_debug_comm_trace hands the whole launch graph out)
+  struct Chan {
+    TraceOps *o;
+    int id;
+  } chan[2] = {{this, 0}, {this, 1}};
+  int ngroups[2] = {0, 0};
+  static int t_begin(void *ctx) {
+    Chan *c = (Chan *)ctx;
+    ++c->o->ngroups[c->id];
+    return 0;
+  }
   static int t_end(void *) { return 0; }
+  void mark_comm(int id, int ch, bool is_send, int peer, size_t bytes) {
+    Op &op = ops[id];
+    op.ch = ch, op.is_send = is_send, op.peer = peer, op.bytes = bytes, op.group = ngroups[ch] - 1;
+  }
+  // every launch of this rank, one per line: "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...>"
+  std::string op_graph() const {
+    std::string out;
+    char b[128];
+    for (size_t i = 0; i < ops.size(); ++i) {
+      const Op &op = ops[i];
+      snprintf(b, sizeof b, "%zu %d %s %d %zu %d ", i, op.ch, op.ch < 0 ? "-" : (op.is_send ? "S" : "R"), op.peer, op.bytes, op.group);
+      out += b;
+      for (size_t d = 0; d < op.deps.size(); ++d) out += (d ? "," : "") + std::to_string(op.deps[d]);
+      out += "\n";
+    }
+    return out;
+  }
   static int t_allreduce(void *, long long *) { return 0; }
   static int t_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream) {
-    TraceOps *o = (TraceOps *)ctx;
+    Chan *c = (Chan *)ctx;
+    TraceOps *o = c->o;
     Acc acc;
     o->touch(acc, buf, bytes, false);
-    o->add(1u << stream_id(stream), "send to rank " + std::to_string(peer), acc);
+    o->mark_comm(o->add(1u << stream_id(stream), "send to rank " + std::to_string(peer), acc), c->id, true, peer, bytes);
     return 0;
   }
   static int t_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream) {
-    TraceOps *o = (TraceOps *)ctx;
+    Chan *c = (Chan *)ctx;
+    TraceOps *o = c->o;
     Acc acc;
     o->touch(acc, buf, bytes, true);
-    o->add(1u << stream_id(stream), "receive from rank " + std::to_string(peer), acc);
+    o->mark_comm(o->add(1u << stream_id(stream), "receive from rank " + std::to_string(peer), acc), c->id, false, peer, bytes);
     return 0;
   }
   // every pair of launches on one slot, one of them writing: the earlier one must be an ancestor of the later one
@@ -300,8 +333,8 @@ struct TraceOps {
 
 // Test hook (include/cholmi.h).  Returns the number of findings (0: every conflicting pair of launches is ordered),
 // < 0 when the walker itself failed; `report` receives the findings, one per line, and a last line with counts.
-extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
-                                              char *report, int cap) {
+static int schedule_check_impl(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling, char *report, int cap,
+                               bool comm_trace) {
   if (nt <= 0 || mb < MACRO || mb % MACRO) return chol_internal_fail(-1, "schedule_check: nt > 0, mb a multiple of 128");
   if (p < 1 || q < 1 || p > MAXP || rank < 0 || rank >= p * q) return chol_internal_fail(-2, "schedule_check: grid");
   WaveGeo g;
@@ -315,7 +348,7 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   if (const char *e = getenv("CHOLMI_CHECK_DROP_GATE")) ops.drop_gate = atoi(e);
   WaveComm cm;
   for (int ch = 0; ch < 2; ++ch) {
-    cm.ch[ch].ctx = &ops;
+    cm.ch[ch].ctx = &ops.chan[ch];
     cm.ch[ch].group_begin = TraceOps::t_begin;
     cm.ch[ch].send = TraceOps::t_send;
     cm.ch[ch].recv = TraceOps::t_recv;
@@ -327,6 +360,12 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   int rc = w.setup();
   if (!rc) rc = w.run(&info);
   if (rc) return rc < 0 ? rc : -rc;
+  if (comm_trace) {  // (the transport calls of this rank, in issue order; the tail if the buffer is short is NOT wanted here)
+    const std::string gr = ops.op_graph();
+    if (!report || (size_t)cap <= gr.size()) return chol_internal_fail(-3, "comm_trace: buffer too small");
+    memcpy(report, gr.c_str(), gr.size() + 1);
+    return (int)ops.findings.size();
+  }
   std::string out;
   for (auto &f : ops.findings) out += f + "\n";
   char tail[200];
@@ -336,6 +375,17 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   if (!ops.dropped.empty()) out += ops.dropped + "\n";
   if (report && cap > 0) snprintf(report, (size_t)cap, "%s", out.size() < (size_t)cap ? out.c_str() : out.substr(out.size() - cap + 1).c_str());
   return (int)ops.findings.size();
+}
+extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
+                                              char *report, int cap) {
+  return schedule_check_impl(nt, mb, p, q, rank, t_tile, t_panel, profiling, report, cap, false);
+}
+// The launch graph of rank `rank` of a p x q grid for one factorisation as text, one launch per line in issue order:
+// "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...>" -- every kernel launch and every transport call with
+// what it waits for (stream order, events, counters), the transport calls with channel, peer, size and the group they
+// were issued in.  tests/test_schedule_check.py replays the graphs of ALL ranks together under RCCL's rules.
+extern "C" int chol_debug_comm_trace(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, char *out, int cap) {
+  return schedule_check_impl(nt, mb, p, q, rank, t_tile, t_panel, 0, out, cap, true);
 }
 extern "C" int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int profiling, char *report, int cap) {
   return chol_debug_schedule_check_grid(nt, mb, 1, 1, 0, t_tile, t_panel, profiling, report, cap);

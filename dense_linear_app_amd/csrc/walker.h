@@ -208,6 +208,17 @@ struct Walker {
   }
 
   // ---- p*q > 1: what moves in wave k, point to point -----------------------------------------
+  // WHAT THE TWO-COMMUNICATOR TRANSPORT RELIES ON (RCCL: channel 0 = diagonal and head tiles on ST_CX, channel 1 = panels
+  // on ST_PX, one communicator each).  (1) Per channel, every rank issues its groups in the order of the waves, and
+  // within a wave diagonal tile before head tile; a send and the receive that meets it are issued for the SAME wave
+  // and kind, and the k-th send from a to b on a channel meets the k-th receive b posts from a.  (2) A rank with nothing
+  // to do in a group issues nothing (WaveComm opens a group at its first operation).  (3) Nothing on the host waits
+  // between two group ends: a group_end enqueues, so every rank gets to post the groups the others are waiting for;
+  // what can block is stream-side only -- a group starts when its stream reaches it and ends when all its operations
+  // have met their partners.  (4) The two channels are ordered against each other only through events of THIS rank
+  // (E_TRSM ahead of the panel's sends, the buffers' last readers), never through the other channel's completion on
+  // another rank.  tests/test_schedule_check.py replays the recorded launch graphs of all ranks of nine grids under
+  // exactly these rules (test_the_transport_calls_of_all_ranks_complete_under_rccl_rules): no cycle.
   // L(k,k) and the inverses of its 128-blocks: owner -> the ranks of its process column that hold panel tiles
   int diag_send(int k, const char *lkk, const char *winv) {
     const int dr = k % g.P, dc = k % g.Q;

@@ -283,6 +283,11 @@ int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int
  * diagonal / head tile buffers by wave parity, the panel buffers by wave mod 4) on the streams they are issued on. */
 int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
                                    char *report, int cap);
+/* ... and that rank's whole launch graph as text, one launch per line in issue order:
+ * "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...>" (kernel launches: channel -1; transport calls: channel
+ * 0 = diagonal and head tiles, 1 = panels, the peer, the size, the group of that channel they were issued in; deps = the
+ * launches it is ordered behind by stream order, events and counters).  Returns the checker's findings, < 0 on error. */
+int chol_debug_comm_trace(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, char *out, int cap);
 
 /* The ordering of the task executor (chol_tile_batch / chol_potrf_batch) checked WITHOUT a GPU.
  * chol_debug_task_record(1, mutate) -- only before chol_init -- puts the executor into recording mode: the grouped-launch

@@ -217,3 +217,111 @@ def test_the_task_executor_check_sees_a_missing_event_wait(drop, monkeypatch):
     """Self-test by mutation: with ONE cross-stream event wait dropped the checker must report an unordered pair."""
     _, (batches, waits, pairs, unordered, hosted), msg = _task_path_record(4096, 512, mutate=drop, monkeypatch=monkeypatch)
     assert unordered > 0 and "without being ordered" in msg, (drop, waits, msg)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The two-communicator transport of a p x q grid, replayed for ALL ranks together under RCCL's rules -- no GPU, no RCCL.
+# What the transport needs to be safe (csrc/walker.h, DESIGN section 5): the operations of one communicator run in the
+# order they were issued on its stream; a group is one fused operation that starts when its stream reaches it and
+# ends when every send and receive in it has met its partner, which must have started too; the k-th send from a to b
+# on a channel pairs with the k-th receive b posts from a on that channel.  The host never waits between groups, so
+# only these stream-side rules can block.  The replay takes every rank's launch graph from the recording engine
+# (chol_debug_comm_trace: every kernel launch and transport call with the launches it is ordered behind) and runs them
+# to completion: a cycle -- rank a's group waiting for a receive that rank b would only post behind a group that waits
+# for a -- shows as "no progress".
+def _launch_graphs(nt, mb, p, q, t_tile, t_panel):
+    import ctypes as C
+
+    from dense_linear_app_amd._lib import lib
+
+    L = lib()
+    graphs = []
+    for rank in range(p * q):
+        buf = C.create_string_buffer(64 << 20)
+        rc = L.chol_debug_comm_trace(nt, mb, p, q, rank, t_tile, t_panel, buf, len(buf))
+        assert rc == 0, (rank, rc)
+        ops = []
+        for ln in buf.value.decode().splitlines():
+            f = ln.split(" ")
+            deps = [int(x) for x in f[6].split(",")] if len(f) > 6 and f[6] else []
+            ops.append({"ch": int(f[1]), "kind": f[2], "peer": int(f[3]), "bytes": int(f[4]), "group": int(f[5]), "deps": deps})
+        graphs.append(ops)
+    return graphs
+
+
+def _replay(graphs):
+    """-> (everything completed?, description of what is stuck)"""
+    from collections import defaultdict, deque
+
+    R = len(graphs)
+    done = [[False] * len(g) for g in graphs]
+    # groups: (rank, channel, group) -> member op ids; FIFO pairing per (src, dst, channel)
+    groups = defaultdict(list)
+    sends, recvs = defaultdict(list), defaultdict(list)
+    for r, g in enumerate(graphs):
+        for i, op in enumerate(g):
+            if op["ch"] >= 0:
+                groups[(r, op["ch"], op["group"])].append(i)
+                (sends if op["kind"] == "S" else recvs)[(r, op["peer"], op["ch"]) if op["kind"] == "S" else (op["peer"], r, op["ch"])].append((r, i))
+    partner = {}
+    for key in set(sends) | set(recvs):
+        a, b = sends.get(key, []), recvs.get(key, [])
+        assert len(a) == len(b), f"rank {key[0]} sends {len(a)} messages to rank {key[1]} on channel {key[2]}, which posts {len(b)} receives"
+        for (rs, i), (rr, j) in zip(a, b):
+            assert graphs[rs][i]["bytes"] == graphs[rr][j]["bytes"], (key, graphs[rs][i], graphs[rr][j])
+            partner[(rs, i)], partner[(rr, j)] = (rr, j), (rs, i)
+    started = set()  # groups whose stream has reached them
+    group_of = {(r, i): (r, graphs[r][i]["ch"], graphs[r][i]["group"]) for (r, c, gidx), m in groups.items() for i in m}
+    progress = True
+    while progress:
+        progress = False
+        for r, g in enumerate(graphs):
+            for i, op in enumerate(g):
+                if done[r][i] or op["ch"] >= 0:
+                    continue
+                if all(done[r][d] for d in op["deps"]):
+                    done[r][i] = True
+                    progress = True
+        for key, members in groups.items():
+            r = key[0]
+            if key not in started:
+                # (a member's dependencies are the group's: the stream's earlier work and what the stream was told to wait
+                # for; members of the same group are not each other's prerequisites)
+                if all(done[r][d] or d in members for i in members for d in graphs[r][i]["deps"]):
+                    started.add(key)
+                    progress = True
+        for key in list(started):
+            r, members = key[0], groups[key]
+            if all(done[r][i] for i in members):
+                continue
+            if all(group_of[partner[(r, i)]] in started for i in members):
+                for i in members:
+                    done[r][i] = True
+                progress = True
+    stuck = [(r, i, graphs[r][i]) for r in range(R) for i in range(len(graphs[r])) if not done[r][i]]
+    return not stuck, stuck[:6]
+
+
+@pytest.mark.parametrize("grid", [(1, 2), (2, 1), (2, 2), (4, 2), (2, 4), (3, 3), (8, 1), (1, 8), (3, 2)])
+@pytest.mark.parametrize("nt,mb,ratio", [(5, 512, 1.0), (9, 512, 0.05), (16, 1024, 3.0), (13, 256, 0.3)])
+def test_the_transport_calls_of_all_ranks_complete_under_rccl_rules(grid, nt, mb, ratio):
+    p, q = grid
+    graphs = _launch_graphs(nt, mb, p, q, 1e-4 * ratio, 1e-4)
+    ok, stuck = _replay(graphs)
+    assert ok, stuck
+    # channel 1 carries one group per wave on every rank that takes part in it, channel 0 the diagonal and head tiles:
+    # the totals over the grid are what SURVEY 8e's messages add up to (every send has its receive: checked in _replay)
+    assert sum(1 for g in graphs for op in g if op["ch"] == 1) > 0
+
+
+def test_the_replay_sees_a_cycle():
+    """Self-test: two ranks that each post a receive ahead of the send the other waits for, on ONE channel, cannot finish."""
+    mk = lambda kind, peer, group, deps: {"ch": 0, "kind": kind, "peer": peer, "bytes": 8, "group": group, "deps": deps}
+    a = [mk("R", 1, 0, []), mk("S", 1, 1, [0])]
+    b = [mk("R", 0, 0, []), mk("S", 0, 1, [0])]
+    ok, stuck = _replay([a, b])
+    assert not ok and len(stuck) == 4
+    # ... and the same calls grouped as RCCL wants them (send and receive of a rank in one group) do
+    a = [mk("R", 1, 0, []), mk("S", 1, 0, [])]
+    b = [mk("R", 0, 0, []), mk("S", 0, 0, [])]
+    assert _replay([a, b])[0]
