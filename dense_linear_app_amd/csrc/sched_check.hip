@@ -41,7 +41,15 @@ struct TraceOps {
     int ch = -1, peer = -1, group = -1;  // a transport call: channel, peer, the group (per channel) it belongs to
     bool is_send = false;
     size_t bytes = 0;
+    char kind = '-';   // P tile POTRF, T panel TRSM, U update launch, Y one-tile SYRK / slices, L latency-form column
+    double cost = 0;   // a rough duration [s] from the calibration the walker was given (scripts/predict_scale.py)
   };
+  double t_tile = 0, t_panel = 0;  // the walker's calibration (seconds per tile update at full-chip rate, per panel chain)
+  // one round of update workgroups (512 of them, nbm^2 per tile at the full-chip rate of one tile per t_tile)
+  double t_round() const { return t_tile * 512.0 / (g.nbm * g.nbm); }
+  void cost_of(int id, char kind, double cost) {
+    if (id >= 0 && id < (int)ops.size()) ops[id].kind = kind, ops[id].cost = cost;
+  }
   std::vector<Op> ops;
   int last_on[ST_COUNT];
   std::set<int> pending[ST_COUNT];       // what the next launch of a stream has to follow beyond the stream's last one
@@ -169,6 +177,7 @@ struct TraceOps {
     touch(pa, lkk, g.tile_bytes, true);
     touch(pa, wv, std::max<size_t>(1, g.winv_bytes), true);
     const int potrf = add(1u << ST_PANEL, "POTRF(" + std::to_string(k) + ")" + (flow ? " [flow: factor]" : ""), pa, extra);
+    cost_of(potrf, 'P', t_panel);
     std::vector<int> after = {potrf};
     if (flow) {
       Acc ra;
@@ -184,12 +193,16 @@ struct TraceOps {
     touch(acc, wv, std::max<size_t>(1, g.winv_bytes), false);
     touch(acc, tiles, (size_t)ntiles * g.tile_bytes, true);
     const int trsm = add(1u << ST_TRSM, "TRSM(" + std::to_string(k) + ")", acc, after);
+    // (pipelined one step behind the POTRF: what is left behind it is one step and the tiles' products beyond what the
+    // steps already did in its shadow)
+    cost_of(trsm, 'T', t_panel / g.nbm + 0.5 * ntiles * t_tile / g.nbm);
     if (ev_head >= 0) ev_deps[ev_head] = {trsm};
     if (sy && sy->c && sy->su) {  // (one GPU: the tiles of a column are contiguous)
       Acc sa;
       touch(sa, tiles, g.tile_bytes, false);
       touch(sa, sy->c, g.tile_bytes, true);
       const int sl = add(1u << ST_U1, "SYRK slices(" + std::to_string(k) + ")", sa, {trsm});
+      cost_of(sl, 'Y', t_panel / g.nbm);
       producer[sy->sem + 32 * (3 * g.nbm)] = sl;
     }
     return 0;
@@ -199,14 +212,15 @@ struct TraceOps {
     touch(acc, lkk, g.tile_bytes, false);
     touch(acc, wv, std::max<size_t>(1, g.winv_bytes), false);
     touch(acc, tiles, (size_t)ntiles * g.tile_bytes, true);
-    add(1u << st, "TRSM(" + std::to_string(k) + ") of " + std::to_string(ntiles) + " tiles [received diagonal tile]", acc);
+    cost_of(add(1u << st, "TRSM(" + std::to_string(k) + ") of " + std::to_string(ntiles) + " tiles [received diagonal tile]", acc), 'T',
+            std::max(t_panel / g.nbm * g.nbm * 0.5, 0.5 * ntiles * t_tile));
     return 0;
   }
   int diag_syrk(int k, int j, char *Cjj, const char *A, int st) {
     Acc acc;
     touch(acc, A, g.tile_bytes, false);
     touch(acc, Cjj, g.tile_bytes, true);
-    add(1u << st, "SYRK(" + std::to_string(j) + "," + std::to_string(j) + ") by panel " + std::to_string(k), acc);
+    cost_of(add(1u << st, "SYRK(" + std::to_string(j) + "," + std::to_string(j) + ") by panel " + std::to_string(k), acc), 'Y', t_round());
     return 0;
   }
   const char *ptile(const PanelRef &p, int i) const {
@@ -217,12 +231,14 @@ struct TraceOps {
     jlo = std::min(jlo, nt), jhi = std::min(jhi, nt);
     Acc acc;
     std::set<int> rows;
+    double tiles_eq = 0;  // GEMM tiles + half the SYRK tiles
     for (int j = jlo; j < jhi; ++j) {
       if (j % g.Q != g.pc) continue;
       for (int i = j; i < nt; ++i) {
         if (i % g.P != g.pr || !(i == j ? (what & 2) : (what & 1))) continue;
         touch(acc, tile(i / g.P, j / g.Q), g.tile_bytes, true);
         rows.insert(i), rows.insert(j);
+        tiles_eq += i == j ? 0.5 * (1.0 + 1.0 / g.nbm) : 1.0;
       }
     }
     if (acc.empty()) return 0;
@@ -233,7 +249,8 @@ struct TraceOps {
     char b[120];
     snprintf(b, sizeof b, "update columns [%d,%d) %sby panel %d%s", jlo, jhi, what == 3 ? "" : what == 1 ? "(off-diagonal) " : "(diagonal) ", k1,
              ps[1] ? (" and " + std::to_string(k2)).c_str() : "");
-    add(1u << st, b, acc);
+    const int np = ps[1] ? 2 : 1;
+    cost_of(add(1u << st, b, acc), 'U', std::max(t_round() * np, tiles_eq * t_tile * np));
     return 0;
   }
   int update_col_small(int k, int st) {
@@ -242,7 +259,7 @@ struct TraceOps {
     touch(acc, tile(k + 1, k), g.tile_bytes, false);
     touch(acc, tile(k + 2, k), (size_t)n * g.tile_bytes, false);
     touch(acc, tile(k + 2, k + 1), (size_t)n * g.tile_bytes, true);
-    add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc);
+    cost_of(add(1u << st, "column " + std::to_string(k + 1) + " (latency form) by panel " + std::to_string(k), acc), 'L', 0.6 * t_round());
     return 0;
   }
   // the transport of a grid: a send reads, a receive writes, on the stream it is issued on; each call also remembers its
@@ -271,7 +288,9 @@ struct TraceOps {
       snprintf(b, sizeof b, "%zu %d %s %d %zu %d ", i, op.ch, op.ch < 0 ? "-" : (op.is_send ? "S" : "R"), op.peer, op.bytes, op.group);
       out += b;
       for (size_t d = 0; d < op.deps.size(); ++d) out += (d ? "," : "") + std::to_string(op.deps[d]);
-      out += "\n";
+      if (op.deps.empty()) out += "-";
+      snprintf(b, sizeof b, " %c %.9f\n", op.kind, op.cost);
+      out += b;
     }
     return out;
   }
@@ -340,6 +359,7 @@ static int schedule_check_impl(int nt, int mb, int p, int q, int rank, double t_
   WaveGeo g;
   g.init(nt, mb, p, q, rank, 8);
   TraceOps ops(g, profiling != 0);
+  ops.t_tile = t_tile, ops.t_panel = t_panel;
   WaveCalib c;
   c.t_tile = t_tile, c.t_panel = t_panel;
   // (self-test of the checker: CHOLMI_CHECK_DROP_WAIT / _DROP_GATE = n makes it ignore the n-th event wait / counter edge the
@@ -381,7 +401,7 @@ extern "C" int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int 
   return schedule_check_impl(nt, mb, p, q, rank, t_tile, t_panel, profiling, report, cap, false);
 }
 // The launch graph of rank `rank` of a p x q grid for one factorisation as text, one launch per line in issue order:
-// "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...>" -- every kernel launch and every transport call with
+// "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...|-> <kind> <rough duration [s]>" -- every kernel launch and every transport call with
 // what it waits for (stream order, events, counters), the transport calls with channel, peer, size and the group they
 // were issued in.  tests/test_schedule_check.py replays the graphs of ALL ranks together under RCCL's rules.
 extern "C" int chol_debug_comm_trace(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, char *out, int cap) {

@@ -284,7 +284,8 @@ int chol_debug_schedule_check(int nt, int mb, double t_tile, double t_panel, int
 int chol_debug_schedule_check_grid(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, int profiling,
                                    char *report, int cap);
 /* ... and that rank's whole launch graph as text, one launch per line in issue order:
- * "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...>" (kernel launches: channel -1; transport calls: channel
+ * "<id> <channel or -1> <S|R|-> <peer> <bytes> <group> <dep,dep,...|-> <kind> <seconds>" (kernel launches: channel -1, kind
+ * P / T / U / Y / L and a rough duration from t_tile / t_panel -- scripts/predict_scale.py; transport calls: channel
  * 0 = diagonal and head tiles, 1 = panels, the peer, the size, the group of that channel they were issued in; deps = the
  * launches it is ordered behind by stream order, events and counters).  Returns the checker's findings, < 0 on error. */
 int chol_debug_comm_trace(int nt, int mb, int p, int q, int rank, double t_tile, double t_panel, char *out, int cap);

@@ -243,7 +243,7 @@ def _launch_graphs(nt, mb, p, q, t_tile, t_panel):
         ops = []
         for ln in buf.value.decode().splitlines():
             f = ln.split(" ")
-            deps = [int(x) for x in f[6].split(",")] if len(f) > 6 and f[6] else []
+            deps = [int(x) for x in f[6].split(",")] if f[6] != "-" else []
             ops.append({"ch": int(f[1]), "kind": f[2], "peer": int(f[3]), "bytes": int(f[4]), "group": int(f[5]), "deps": deps})
         graphs.append(ops)
     return graphs
