@@ -1466,6 +1466,38 @@ struct DiagLds {
   int failed;
 };
 
+// The 128 x 128 block at A (leading dimension ld) into the LDS image S (lower 16 x 16 blocks, db_off), zeros above the
+// diagonal inside the diagonal blocks.  256 threads; lane rp of wave w4 owns rows 2 rp, 2 rp + 1 (one 16-byte global load
+// per column: a wave instruction fetches a whole 128-row column) of the block columns w4 and 7 - w4 -- nine of the 36
+// lower blocks per wave; all 32 loads of a lane in flight at once (the kernel starts cold, behind the launch that
+// produced the block: latency, not bandwidth).
+template <typename T>
+__device__ __forceinline__ void load_block_lower(const T *__restrict__ A, int ld, T *S) {
+  typedef T pair2_t __attribute__((ext_vector_type(2)));
+  constexpr int NB = 16;
+  const int t = threadIdx.x, i0 = 2 * (t & 63), br = i0 >> 4, w4 = t >> 6, r = i0 & 15;
+  pair2_t v[2][16];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = h ? 7 - w4 : w4;
+    const T *src = A + i0 + (size_t)(NB * c) * ld;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      v[h][u] = pair2_t{T(0), T(0)};
+      if (br > c || (br == c && r + 1 >= u)) v[h][u] = *reinterpret_cast<const pair2_t *>(src + (size_t)u * ld);
+      if (br == c && r < u) v[h][u][0] = T(0);  // (row r is above the diagonal in this column, row r + 1 is on it)
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = h ? 7 - w4 : w4;
+    if (br < c) continue;
+    T *dst = S + db_off(br, c) + r;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[h][u][0], dst[u * DB_LD + 1] = v[h][u][1];
+  }
+}
+
 // FLOW (k_flow_factor): the block is already in L.S (loaded, and updated by the earlier steps' products, by the
 // caller); every finished 16-column panel of the factor and the inverse of its 16 x 16 diagonal block are
 // PUBLISHED for the row-slab waves of k_flow_rows -- write-through (sc1) stores into the tile / winv right after
@@ -1492,27 +1524,12 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   // block the 16 elements of its row are one base address + constant strides on both sides
   // (no per-element index arithmetic), 16 independent accesses in flight, rows of consecutive
   // threads contiguous in global memory.
-  const int gi = t & (n - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
-  if constexpr (!FLOW) {
-    // all four block columns of the row at once: up to 64 independent loads in flight per thread
-    // (the kernel starts cold, behind the launch that produced the block: latency, not bandwidth)
-    T v[4][16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = gc0 + q;
-      const T *src = A + gi + (size_t)(NB * c) * ld;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[q][u] = (gr > c || (gr == c && (gi & 15) >= u)) ? src[(size_t)u * ld] : T(0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = gc0 + q;
-      if (gr < c) continue;
-      T *dst = S + db_off(gr, c) + (gi & 15);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
-    }
-  }
+  // Global <-> LDS, two ROWS per lane (16 bytes on the global side: one wave instruction moves a whole 128-row column):
+  // lane rp of wave w4 owns rows 2 rp, 2 rp + 1 of the block columns w4 and 7 - w4 (nine of the 36 lower blocks per
+  // wave); per block the pair's 16 columns are one base address + constant strides on both sides.
+  typedef T pair2_t __attribute__((ext_vector_type(2)));
+  const int gi0 = 2 * (t & 63), gbr = gi0 >> 4, gw4 = t >> 6;
+  if constexpr (!FLOW) load_block_lower<T>(A, ld, S);
   if constexpr (!FLOW) {
     if (t < 16) L.Lrinv[t] = T(0);
     if (t == 0) failed = 0;
@@ -1828,17 +1845,22 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
       ph[1] = tA;
       ph[2] = tB;
     }
+    if constexpr (!FLOW) {  // (FLOW: every panel was stored when it was published)
 #pragma unroll 1
-    for (int c = gc0; c < (FLOW ? gc0 : gc0 + 4); ++c) {  // (FLOW: every panel was stored when it was published)
-      if (gr < c) continue;
-      T v[16];
-      const T *src = S + db_off(gr, c) + (gi & 15);
+      for (int h = 0; h < 2; ++h) {
+        const int c = h ? 7 - gw4 : gw4;
+        if (gbr < c) continue;
+        pair2_t v[16];
+        const T *src = S + db_off(gbr, c) + (gi0 & 15);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = src[u * DB_LD];
-      T *dst = A + gi + (size_t)(NB * c) * ld;
+        for (int u = 0; u < 16; ++u) v[u] = pair2_t{src[u * DB_LD], src[u * DB_LD + 1]};
+        T *dst = A + gi0 + (size_t)(NB * c) * ld;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (gr > c || (gi & 15) >= u) dst[(size_t)u * ld] = v[u];
+        for (int u = 0; u < 16; ++u) {
+          if (gbr > c || (gi0 & 15) >= u) *reinterpret_cast<pair2_t *>(dst + (size_t)u * ld) = v[u];
+          else if ((gi0 & 15) + 1 >= u) dst[(size_t)u * ld + 1] = v[u][1];
+        }
+      }
     }
   }
   if (ph && t == 0) ph[3] = PH_NOW();  // L stored
@@ -1874,23 +1896,27 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
   if (ph && t == 0) ph[5] = PH_NOW();  // phase C done
 #undef PH_NOW
 #pragma unroll 1
-  for (int c = gc0; c < gc0 + 4; ++c) {  // winv: full 128 x 128, zero above the diagonal
-    T v[16];
+  for (int h = 0; h < 2; ++h) {  // winv: full 128 x 128, zero above the diagonal
+    const int c = h ? 7 - gw4 : gw4;
+    pair2_t v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = T(0);
-    if (gr == c) {
+    for (int u = 0; u < 16; ++u) v[u] = pair2_t{T(0), T(0)};
+    if (gbr == c) {
       const T *src = Wd[c];
+      const int r = gi0 & 15;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if ((gi & 15) >= u) v[u] = src[wd_idx(gi & 15, u)];
-    } else if (gr > c) {
-      const T *src = S + db_off(gr, c) + (gi & 15);
+      for (int u = 0; u < 16; ++u) {
+        if (r >= u) v[u][0] = src[wd_idx(r, u)];
+        if (r + 1 >= u) v[u][1] = src[wd_idx(r + 1, u)];
+      }
+    } else if (gbr > c) {
+      const T *src = S + db_off(gbr, c) + (gi0 & 15);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = src[u * DB_LD];
+      for (int u = 0; u < 16; ++u) v[u] = pair2_t{src[u * DB_LD], src[u * DB_LD + 1]};
     }
-    T *dst = winv + gi + (size_t)(NB * c) * n;
+    T *dst = winv + gi0 + (size_t)(NB * c) * n;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) dst[(size_t)u * n] = v[u];
+    for (int u = 0; u < 16; ++u) *reinterpret_cast<pair2_t *>(dst + (size_t)u * n) = v[u];
   }
 }
 
@@ -2113,25 +2139,9 @@ __global__ __launch_bounds__(256, 2) void k_flow_factor(T *tile, int mb, int nbm
     if (slot_s < 1000) ph = dbg + 1 + 8 * slot_s + 2;
   }
   T *A = tile + (size_t)s * MACRO * (mb + 1);
-  {  // the block as the previous waves' updates left it -> L.S (potrf_diag_body's own loader, see there)
-    constexpr int NB = 16;
-    const int t = threadIdx.x, gi = t & (MACRO - 1), gr = gi >> 4, gc0 = 4 * (t >> 7);
-    T v[4][16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = gc0 + q;
-      const T *src = A + gi + (size_t)(NB * c) * mb;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[q][u] = (gr > c || (gr == c && (gi & 15) >= u)) ? src[(size_t)u * mb] : T(0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = gc0 + q;
-      if (gr < c) continue;
-      T *dst = L.S + db_off(gr, c) + (gi & 15);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) dst[u * DB_LD] = v[q][u];
-    }
+  {  // the block as the previous waves' updates left it -> L.S
+    const int t = threadIdx.x;
+    load_block_lower<T>(A, mb, L.S);
     if (t < 16) L.Lrinv[t] = T(0);
     if (t == 0) L.failed = 0;
     __syncthreads();
