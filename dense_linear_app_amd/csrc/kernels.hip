@@ -24,6 +24,14 @@
 
 #include <type_traits>
 
+// The device code is written for gfx950 and nothing else: the fp64 / fp32 16x16x4 MFMA layouts, LDS-DMA, and -- what a
+// silent retarget would break without a compile error -- hand-offs that rely on this family's in-order VMEM return and
+// `sc1` write-through stores instead of release / acquire fences (the flow form of the tile POTRF, the phase-A flags in
+// LDS), and inline-asm sequences whose wait states were counted for it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libcholmi's kernels target gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace cholmi {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
