@@ -103,7 +103,12 @@ def lib() -> C.CDLL:
         "chol_dist_gather_lower": ([vp, vp, i], i),
     }
     for name, (argt, rest) in sig.items():
-        fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
+        try:
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
+        except AttributeError:
+            if os.environ.get("LIBCHOLMI_PATH"):  # (an OLDER build for an A/B run may lack the newest diagnostics)
+                continue
+            raise
         fn.argtypes = argt
         fn.restype = rest
     _lib = L
