@@ -1602,6 +1602,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             constexpr unsigned long long M = (0xFFFFull & ~((2ull << jj) - 1ull)) << (16 * K);
             const T d = dcur;
             T rinvn;                 // -1 / sqrt(d)
+            [[maybe_unused]] T sq32 = T(0);
             T Em, as = T(0), xs = T(0);
             // what the rest of the pivot needs of E (as the previous MFMA left it): row jj beyond the diagonal, zero in
             // every other lane (selected ahead of the product: the MFMA must not read a register an inline-asm
@@ -1633,8 +1634,8 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
               h = __builtin_fma(h, e, h);
               rinvn = (T)(-h - h);
             } else {
-              T sq, rinv;
-              sqrt_rsqrt(d, sq, rinv);
+              T rinv;
+              sqrt_rsqrt(d, sq32, rinv);
               asm volatile("" : "+v"(rinv));
               reads();
               asm volatile("" : "+v"(rinv), "+v"(Em), "+s"(as), "+s"(xs));
@@ -1652,6 +1653,9 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
             // at the end of the panel, the strict upper triangle is never read), then -1/pivot, wave-uniform (every
             // lane stores it: same address, same value) -- the column's flag: DS operations of one wave execute in order
             lds_store_lanes<jj * DB_LD * (int)sizeof(T)>((unsigned)(size_t)(Lc + lo_), a, 0xFFFFull << (16 * K));
+            // fp32: the diagonal entry at once, from the pivot the chain used (the fp32 MFMA does not round like an fma, so
+            // the diagonal of E may differ from it in the last bit -- near a zero pivot that could be the sign)
+            if constexpr (sizeof(T) == 4) Lc[jj * (DB_LD + 1)] = sq32;
             Lr[jj] = rinvn;
             asm volatile("" ::: "memory");
           });
@@ -1678,7 +1682,7 @@ __device__ __forceinline__ void potrf_diag_body(T *A, int ld, T *__restrict__ wi
                 atomicCAS(info, 0, info_base + j0 + bad);
                 failed = 1;
               }
-            } else if (mine) {
+            } else if (mine && sizeof(T) == 8) {
               T sq;
               if constexpr (sizeof(T) == 8) {
                 const double r = __builtin_amdgcn_rsq((double)d);
