@@ -8,6 +8,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 static PyObject *s_result_id, *s_name, *s_session_id, *s_data, *s_status, *s_created, *s_completed, *s_pending,
@@ -373,6 +374,24 @@ static uint64_t tag_of(const char *p, Py_ssize_t n) {
  * bytes; everything else is returned in `fallback` (indices) for the one-task path, whose messages are the reference's.
  * groups: {(launch class, B, urgent): ([task index], [ptr0], [ptr1], [ptr2], [tag])}, launch class 1 TRSM, 2 SYRK and
  * GEMM together, 4 POTRF; urgent = TaskOptions.priority > 1. */
+/* one resolved task of a batch: its group, operand addresses, content tag */
+typedef struct {
+  int group;
+  Py_ssize_t idx;
+  unsigned long long ptr[3], tag;
+} resolved_t;
+static int by_l_then_index(const void *pa, const void *pb) {  /* TRSM: tasks that share an L side by side (ascending L, stable) */
+  const resolved_t *a = (const resolved_t *)pa, *b = (const resolved_t *)pb;
+  if (a->ptr[1] != b->ptr[1]) return a->ptr[1] < b->ptr[1] ? -1 : 1;
+  return a->idx < b->idx ? -1 : (a->idx > b->idx);
+}
+static int syrk_last_then_index(const void *pa, const void *pb) {  /* updates: the SYRK tasks (no second operand) last, stable */
+  const resolved_t *a = (const resolved_t *)pa, *b = (const resolved_t *)pb;
+  const int sa = a->ptr[2] == 0, sb = b->ptr[2] == 0;
+  if (sa != sb) return sa - sb;
+  return a->idx < b->idx ? -1 : (a->idx > b->idx);
+}
+
 static PyObject *resolve_batch(PyObject *self, PyObject *args) {
   PyObject *tasks, *results, *blob_cls;
   Py_buffer buf, ops, Bs, ioff, ilen;
@@ -384,7 +403,14 @@ static PyObject *resolve_batch(PyObject *self, PyObject *args) {
   PyObject *groups = PyDict_New(), *fallback = PyList_New(0), *ret = NULL;
   const int32_t *op = (const int32_t *)ops.buf, *Bv = (const int32_t *)Bs.buf, *il = (const int32_t *)ilen.buf;
   const int64_t *io = (const int64_t *)ioff.buf;
-  if (!groups || !fallback) goto done;
+  enum { MAXG = 32 };
+  int gcode[MAXG], gB[MAXG], gurgent[MAXG], gcount[MAXG], ng = 0;
+  resolved_t *rs = (resolved_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(resolved_t));
+  Py_ssize_t nr = 0;
+  if (!groups || !fallback || !rs) {
+    if (!rs) PyErr_NoMemory();
+    goto done;
+  }
   if (ops.len < (Py_ssize_t)(n * 4) || Bs.len < (Py_ssize_t)(n * 4) || ioff.len < (Py_ssize_t)(n * 24) || ilen.len < (Py_ssize_t)(n * 12)) {
     PyErr_SetString(PyExc_ValueError, "resolve_batch: parse arrays shorter than the task list");
     goto done;
@@ -431,6 +457,22 @@ static PyObject *resolve_batch(PyObject *self, PyObject *args) {
       Py_DECREF(rid);
     }
     Py_XDECREF(deps);
+    int g = -1;
+    if (ok) {
+      PyObject *opt = PyObject_GetAttr(t, s_options), *pr = opt ? PyObject_GetAttr(opt, s_priority) : NULL;
+      Py_XDECREF(opt);
+      if (!pr) goto done;
+      const long prio = PyLong_AsLong(pr);
+      Py_DECREF(pr);
+      if (prio == -1 && PyErr_Occurred()) goto done;
+      const int gc = code == 3 ? 2 : code, urgent = prio > 1;
+      for (g = 0; g < ng; ++g)
+        if (gcode[g] == gc && gB[g] == B && gurgent[g] == urgent) break;
+      if (g == ng) {
+        if (ng == MAXG) ok = 0, g = -1;  /* (more launch classes in one call than anybody submits: the one-task path takes the rest) */
+        else gcode[ng] = gc, gB[ng] = B, gurgent[ng] = urgent, gcount[ng] = 0, ++ng;
+      }
+    }
     if (!ok) {
       PyObject *ix = PyLong_FromSsize_t(i);
       if (!ix || PyList_Append(fallback, ix)) {
@@ -440,35 +482,49 @@ static PyObject *resolve_batch(PyObject *self, PyObject *args) {
       Py_DECREF(ix);
       continue;
     }
-    PyObject *opt = PyObject_GetAttr(t, s_options), *pr = opt ? PyObject_GetAttr(opt, s_priority) : NULL;
-    Py_XDECREF(opt);
-    if (!pr) goto done;
-    const long prio = PyLong_AsLong(pr);
-    Py_DECREF(pr);
-    if (prio == -1 && PyErr_Occurred()) goto done;
-    PyObject *key = Py_BuildValue("(iiO)", code == 3 ? 2 : code, B, prio > 1 ? Py_True : Py_False);
-    if (!key) goto done;
-    PyObject *g = PyDict_GetItemWithError(groups, key);
-    if (!g) {
-      if (PyErr_Occurred() || !(g = Py_BuildValue("([][][][][])")) || PyDict_SetItem(groups, key, g)) {
-        Py_XDECREF(g);
-        Py_DECREF(key);
-        goto done;
+    resolved_t *r = rs + nr++;
+    r->group = g, r->idx = i, r->ptr[0] = ptr[0], r->ptr[1] = ptr[1], r->ptr[2] = ptr[2], r->tag = tag;
+    ++gcount[g];
+  }
+  /* per launch class: the task indices in launch order and the 5 x m table of 64-bit words (c_in, a, b, c_out -- filled
+   * in by the caller once the outputs are allocated --, tag) that chol_tile_batch / chol_potrf_batch take, as a bytearray */
+  for (int g = 0; g < ng; ++g) {
+    const Py_ssize_t m = gcount[g];
+    resolved_t *sel = (resolved_t *)malloc((size_t)m * sizeof(resolved_t));
+    if (!sel) {
+      PyErr_NoMemory();
+      goto done;
+    }
+    Py_ssize_t q = 0, nsyrk = 0;
+    for (Py_ssize_t i = 0; i < nr; ++i)
+      if (rs[i].group == g) sel[q++] = rs[i];
+    if (gcode[g] == 1) qsort(sel, (size_t)m, sizeof(resolved_t), by_l_then_index);
+    else if (gcode[g] == 2) qsort(sel, (size_t)m, sizeof(resolved_t), syrk_last_then_index);
+    PyObject *idxs = PyList_New(m), *raw = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)(5 * m * 8));
+    int bad = !idxs || !raw;
+    if (!bad) {
+      unsigned long long *w = (unsigned long long *)PyByteArray_AS_STRING(raw);
+      for (q = 0; q < m && !bad; ++q) {
+        w[q] = sel[q].ptr[0], w[m + q] = sel[q].ptr[1], w[2 * m + q] = sel[q].ptr[2], w[3 * m + q] = 0, w[4 * m + q] = sel[q].tag;
+        if (gcode[g] == 2 && sel[q].ptr[2] == 0) ++nsyrk;
+        PyObject *ix = PyLong_FromSsize_t(sel[q].idx);
+        if (!ix) bad = 1;
+        else PyList_SET_ITEM(idxs, q, ix);
       }
-      Py_DECREF(g);
     }
-    Py_DECREF(key);
-    PyObject *vals[5] = {PyLong_FromSsize_t(i), PyLong_FromUnsignedLongLong(ptr[0]), PyLong_FromUnsignedLongLong(ptr[1]),
-                         PyLong_FromUnsignedLongLong(ptr[2]), PyLong_FromUnsignedLongLong(tag)};
-    int bad = 0;
-    for (int q = 0; q < 5; ++q) {
-      if (!vals[q] || PyList_Append(PyTuple_GET_ITEM(g, q), vals[q])) bad = 1;
-      Py_XDECREF(vals[q]);
-    }
+    free(sel);
+    PyObject *key = bad ? NULL : Py_BuildValue("(iiO)", gcode[g], gB[g], gurgent[g] ? Py_True : Py_False);
+    PyObject *val = key ? Py_BuildValue("(OOn)", idxs, raw, nsyrk) : NULL;
+    if (!val || PyDict_SetItem(groups, key, val)) bad = 1;
+    Py_XDECREF(key);
+    Py_XDECREF(val);
+    Py_XDECREF(idxs);
+    Py_XDECREF(raw);
     if (bad) goto done;
   }
   ret = Py_BuildValue("(OO)", groups, fallback);
 done:
+  free(rs);
   Py_XDECREF(groups);
   Py_XDECREF(fallback);
   PyBuffer_Release(&buf);
@@ -629,7 +685,7 @@ static PyMethodDef methods[] = {
     {"payload_join", payload_join, METH_VARARGS, "payload_join(tasks, results) -> (buf, offsets) or None"},
     {"submit", submit, METH_VARARGS, "submit(tasks, pending, results, tcs, task_cls, prefix, start, session, options) -> [task ids]"},
     {"split_ready", split_ready, METH_VARARGS, "split_ready(pending, tasks, results, batch_partitions) -> ({partition: [tasks]}, rest)"},
-    {"resolve_batch", resolve_batch, METH_VARARGS, "resolve_batch(tasks, results, buf, ops, Bs, id_off, id_len, blob_cls, async_potrf) -> (groups, fallback)"},
+    {"resolve_batch", resolve_batch, METH_VARARGS, "resolve_batch(tasks, results, buf, ops, Bs, id_off, id_len, blob_cls, async_potrf) -> ({(code, B, urgent): (task indices in launch order, bytearray of the 5 x m operand table, number of SYRK tasks)}, fallback)"},
     {"complete_batch", complete_batch, METH_VARARGS, "complete_batch(tasks, idxs, results, blob_cls, parent, base, tb, epoch, out, ok_status) -> [output ids]"},
     {"book_batch", book_batch, METH_VARARGS, "book_batch(tasks, statuses, results, executed, ok_status) -> [slow indices]"},
     {"task_creations", task_creations, METH_VARARGS, "task_creations(cls, payload_ids, output_ids, items) -> [TaskCreation]"},

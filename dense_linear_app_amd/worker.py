@@ -490,12 +490,31 @@ class DagCholeskyWorker(ArmoniKWorker):
         if groups:
             be.sync_inputs()  # uploads made through torch are visible to the library's streams
         ok_status = ProcessStatus.Ok
-        for (code, B, urgent), (idxs, p0, p1, p2, tags) in sorted(groups.items(), key=lambda kv: not kv[0][2]):  # the chain's first
-            m = len(idxs)
+        for (code, B, urgent), grp in sorted(groups.items(), key=lambda kv: not kv[0][2]):  # the chain's first
             tb = B * B * 8
+            if fast is not None:
+                # (the C loop hands over the operand table in launch order: TRSM tasks that share an L side by side, the SYRK
+                # tasks of an update last)
+                idxs, raw, nsyrk = grp
+                m = len(idxs)
+                ptr = np.frombuffer(raw, dtype=np.uint64).reshape(5, m)
+            else:
+                idxs, p0, p1, p2, tags = grp
+                m = len(idxs)
+                ptr = np.empty((5, m), dtype=np.uint64)
+                ptr[0], ptr[1], ptr[2], ptr[4] = p0, p1, p2, tags
+                nsyrk = 0
+                if code != 4:
+                    if code == 1:  # panels: the tasks that share an L side by side
+                        order = np.argsort(ptr[1], kind="stable")
+                    else:  # the SYRK tasks (no second operand) last: their blocks above the diagonal only copy, and a tile
+                        # whose workgroups leave early in the middle of a launch costs the L2 its operand reuse
+                        order = np.argsort(ptr[2] == 0, kind="stable")
+                        nsyrk = int(np.count_nonzero(ptr[2] == 0))
+                    ptr[:3] = ptr[:3, order]
+                    ptr[4] = ptr[4, order]
+                    idxs = [idxs[o] for o in order.tolist()]
             res, base = be.batch_alloc(m, B)
-            ptr = np.empty((5, m), dtype=np.uint64)
-            ptr[0], ptr[1], ptr[2], ptr[4] = p0, p1, p2, tags
             ptr[3] = np.arange(base, base + tb * m, tb, dtype=np.uint64)
             slots = None
             if code == 4:  # POTRF: enqueued, the output tagged with its result id, info left in a device slot
@@ -505,16 +524,6 @@ class DagCholeskyWorker(ArmoniKWorker):
                 rc = be.potrf_batch(B, m, ptr, slots)
                 opname, flops = "POTRF", (1.0 / 3.0) * m * B * B * B
             else:
-                if code == 1:  # panels: the tasks that share an L side by side
-                    order = np.argsort(ptr[1], kind="stable")
-                    nsyrk = 0
-                else:  # the SYRK tasks (no second operand) last: their blocks above the diagonal only copy, and a tile
-                    # whose workgroups leave early in the middle of a launch costs the L2 its operand reuse
-                    order = np.argsort(ptr[2] == 0, kind="stable")
-                    nsyrk = int(np.count_nonzero(ptr[2] == 0))
-                ptr[:3] = ptr[:3, order]
-                ptr[4] = ptr[4, order]
-                idxs = [idxs[o] for o in order.tolist()]
                 t0 = time.perf_counter()
                 rc = be.tile_batch(1 if code == 1 else 4, B, m, ptr, urgent)
                 opname = "TRSM" if code == 1 else ("SYRK" if nsyrk == m else "GEMM")
