@@ -172,12 +172,14 @@ def _task_path_record(N, B, mutate=-1, retire_bytes=None, monkeypatch=None):
         nxt = 1 << 30
         def sync_inputs(self): pass
         def batch_alloc(self, m, B):
+            base = Backend.nxt  # (fresh addresses, never reused: results are write-once)
             Backend.nxt += m * B * B * 8
-            return _Fake(m * B * B * 8, Backend.nxt), Backend.nxt
+            return _Fake(m * B * B * 8, base), base
 
     def fake_from_bytes(cls, data):
+        base = Backend.nxt
         Backend.nxt += len(data)
-        return cls(_Fake(len(data), Backend.nxt))
+        return cls(_Fake(len(data), base))
 
     L = lib()
     assert L.chol_debug_task_record(1, mutate) == 0
