@@ -169,8 +169,20 @@ class HipTileBackend:
         """One allocation for the m output tiles of a grouped launch -> (owner, device address)."""
         import torch
 
-        res = torch.empty(m * B * B, dtype=torch.float64, device="cuda")
+        # Carved from 1 GiB slabs (a slab lives as long as a blob of it does): a factorisation's batches come in hundreds of
+        # different sizes, and asked for one by one they end in hipMalloc calls -- which synchronise the device and, in
+        # the first process on a fresh box, take long enough to make a run 2.5-9x slower (16 against 43 TFLOP/s at
+        # N=16384 / tile 512, seen three times in round 5); slabs of one size are served from torch's cache.
+        n = m * B * B
+        slab = getattr(self, "_slab", None)
+        if slab is None or self._slab_off + n > slab.numel():
+            slab = self._slab = torch.empty(max(n, self.SLAB_ELEMS), dtype=torch.float64, device="cuda")
+            self._slab_off = 0
+        res = slab[self._slab_off:self._slab_off + n]
+        self._slab_off += n
         return res, res.data_ptr()
+
+    SLAB_ELEMS = (1 << 30) // 8
 
     def tile_batch(self, code: int, B: int, m: int, ptr, urgent: bool = False) -> int:
         """code: 1 TRSM, 4 UPDATE (the SYRK and GEMM tasks of a wave in ONE out-of-place launch; ptr[2] == 0 marks a SYRK
