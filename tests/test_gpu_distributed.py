@@ -55,6 +55,40 @@ def test_pxq_rehearsal_on_one_gpu(P, Q, N, B, dtype, cham, orc):
     ch.CHAMELEON_Desc_Destroy(full)
 
 
+@pytest.mark.parametrize("N,dtype,tol", [(65536, "f64", 1e-13), (131072, "f32", 5e-5)])
+def test_baseline_configs_4_and_5_partitioned_for_8_gpus_at_full_size(N, dtype, tol, cham):
+    """BASELINE configs 4 and 5 name a 2D block-cyclic partitioning over 8 GPUs.  There is one GPU here: the 4 x 2 walker of
+    all eight ranks (threads, stream-ordered copies, no device synchronisation: chol_dist_rehearse) at the FULL size, the
+    gathered factor checked by its residual; fp64 also against the one-GPU walker's factor of the same matrix, on the
+    device, with the driver's own operations (dlacpy Lower, dgeadd, dlange Max).  scripts/rehearse_full_size.py does the
+    same for 2 x 4 as well (profiles/r05_rehearse_full_size.txt)."""
+    import torch
+
+    from dense_linear_app_amd import distributed as dd
+
+    ch = cham
+    B = 1024
+    info, full, ms = dd.rehearse(N, B, 4, 2, dtype)
+    assert info == 0
+    assert ch.residual_plgsy(full, float(N), 42) <= tol
+    if dtype == "f64":
+        mk = lambda: ch.CHAMELEON_Desc_Create(None, ch.ChamRealDouble, B, B, B * B, N, N, 0, 0, N, N, 1, 1)
+        ref, t1, t2 = mk(), mk(), mk()
+        ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, ref, 42)
+        assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, ref) == 0
+        for t in (t1, t2):
+            ch.CHAMELEON_dgeadd_Tile(ch.ChamNoTrans, 0.0, t, 0.0, t)
+        ch.CHAMELEON_dlacpy_Tile(ch.ChamLower, ref, t1)
+        ch.CHAMELEON_dlacpy_Tile(ch.ChamLower, full, t2)
+        scale = ch.CHAMELEON_dlange_Tile(ch.ChamMaxNorm, t1)
+        ch.CHAMELEON_dgeadd_Tile(ch.ChamNoTrans, -1.0, t2, 1.0, t1)
+        assert ch.CHAMELEON_dlange_Tile(ch.ChamMaxNorm, t1) / scale <= 1e-12
+        for t in (ref, t1, t2):
+            ch.CHAMELEON_Desc_Destroy(t)
+    ch.CHAMELEON_Desc_Destroy(full)
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("P,Q,N,B", [(2, 2, 2000, 256), (2, 3, 1500, 192)])
 def test_pxq_rehearsal_ragged_order_and_odd_tiles(P, Q, N, B, cham, orc):
     """N not a multiple of the tile, tile not a multiple of 128, on a p x q grid: every rank keeps its padded image."""
