@@ -1,5 +1,7 @@
 // The decoupled pivot loop of phase A (kernels.hip, wave 0) in isolation: cycles per pivot of variants.
 // Build: hipcc --offload-arch=gfx950 -O3 -o rank1_probe2 rank1_probe2.hip
+// (with __launch_bounds__(64, 2) on k_piv the compiler picks VGPR-form MFMAs: 244 instead of 261 cycles per pivot, and WRONG
+//  results -- the inline-asm v_cndmask then reads the MFMA's destination with no hazard wait: DESIGN.md section 9)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
