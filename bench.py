@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-extra-N", type=int, default=20480)
     ap.add_argument("--no-check", action="store_true",
                     help="skip the (untimed) residual of the last step's factor; by default it is in the line")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC pass instead of two child runs under rocprofv3 --pmc")
     ap.add_argument("--no-worker-path", action="store_true",
                     help="skip the task-API leg (the same factorisation submitted task by task through the in-process "
                          "ArmoniK-style client / worker at N=16384, tile 512; ~6 s)")
@@ -138,6 +140,55 @@ def worker_path(N: int, B: int) -> dict:
             "submit_seconds": round(best.submit_seconds, 4), "host_us_per_task": round(best.submit_seconds / n * 1e6, 2),
             "tile00_max_rel_err": float(np.abs(L00 - ref).max() / np.abs(ref).max()),
             "what": "client.run_cholesky_dag(device_results=True, batched=True): wave-level execution behind the task API"}
+
+
+def live_pmc_traffic(a, budget_s: float = 150.0):
+    """HBM bytes per launch of the update kernel, MEASURED for this run's workload: two child runs of this script (one
+    factorisation, nothing else) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters
+    in KiB, FETCH doubled (MI355X_MICROARCH.md, HBM section).  Children, because the profiler's tool library has to be
+    in the process from its start; the program comes straight after `--`.  -> (bytes per launch, launches, note) or
+    None when rocprofv3 is not there, a pass fails or the budget runs out (the committed figure is used then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    t_end = time.time() + budget_s
+    tot, launches = {}, 0
+    tmp = tempfile.mkdtemp(prefix="cholmi_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = t_end - time.time()
+            if left < 20:
+                return None
+            out = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--N", str(a.N), "--tile", str(a.tile), "--dtype", a.dtype, "--seed", str(a.seed), "--steps", "1", "--warmup", "0",
+                   "--no-cpu-baseline", "--no-worker-path", "--no-check", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            if p.returncode != 0:
+                return None
+            s, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_trail_update" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        s += float(r["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None
+            tot[ctr], launches = s, n
+        # (one un-timed and one bracketed factorisation per child: `launches` counts both)
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / launches, launches, \
+            "measured in this run: child passes under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB, FETCH doubled per the gfx950 correction)"
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def load_pmc_traffic():
@@ -507,14 +558,19 @@ def main() -> int:
             traffic = load_pmc_traffic()
             static = (traffic["hbm_bytes_per_launch"] * traffic["launches"] / (r["upd_launches"] / a.steps)) \
                 if traffic and traffic.get("N") == a.N and traffic.get("tile") == a.tile else None
+            traffic_source = "profiles/pmc_traffic.json (committed PMC pass, not measured in this run)" if static else None
+            live = None if a.no_live_traffic else live_pmc_traffic(a)
+            if live:
+                static, traffic_source = live[0], live[2]
             line["roofline"] = {
                 "bound": "mfma", "kernel": r["kernel"], "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # the register-only MFMA stream measured in this run: what the chip sustains, beside the datasheet peak
                 "peak_probe": round(r["probe"], 2), "frac_of_probe": round(ach / r["probe"], 4) if r["probe"] > 0 else None,
-                # HBM bytes per launch from the committed rocprofv3 --pmc pass of this workload (profiles/pmc_traffic.json:
-                # one factorisation, rescaled to THIS run's launch count) -- static, not collected in this run
-                "traffic": static, "traffic_source": "profiles/pmc_traffic.json (committed PMC pass, not measured in this run)" if static else None,
+                # HBM bytes per launch of the update kernel: measured by two child passes under rocprofv3 --pmc when they fit
+                # the run's budget (live_pmc_traffic), else the committed pass of this workload (profiles/pmc_traffic.json,
+                # rescaled to THIS run's launch count) -- traffic_source says which
+                "traffic": static, "traffic_source": traffic_source,
                 "launches": r["upd_launches"], "avg_launch_ms": round(r["upd_ms"] / max(1, r["upd_launches"]), 4),
                 "flops_per_launch": r["upd_flops"] / max(1, r["upd_launches"]),
                 # the launches of a wave run side by side: the HIP-event brackets

@@ -11,7 +11,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/pmcb_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--N $N --tile $tile --dtype $dtype --steps 1 --warmup 0 --no-cpu-baseline --no-worker-path --no-check"
+args="--N $N --tile $tile --dtype $dtype --steps 1 --warmup 0 --no-cpu-baseline --no-worker-path --no-live-traffic --no-check"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" $args > "$out/trace.log" 2>&1
 p1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE"
 p2="SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS TCC_HIT_sum TCC_MISS_sum"

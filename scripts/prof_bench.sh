@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/benchprof_$tag
 mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-worker-path "$@" > "$root/gpurun_out/benchprof_$tag.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-worker-path --no-live-traffic "$@" > "$root/gpurun_out/benchprof_$tag.log" 2>&1
 cd "$root"
 f=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "gpurun_out/bench_${tag}_kernel_stats.csv"

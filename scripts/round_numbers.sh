@@ -5,7 +5,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"
 out=gpurun_out/numbers.txt
 : > $out
-run() { python bench.py --no-cpu-baseline --no-worker-path "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); r=d.get('roofline',{}); n=d['config']['N']; print(n, d['config']['tile'], d['dtype'], d['value'], 'TF/s', d['pct_of_mfma_peak'], '% of peak; update kernel', r.get('achieved'), 'steps', d['steps'], '; one more step without the event brackets:', round(n**3/3/(d['unprofiled_ms']*1e-3)/1e12, 2), 'TF/s')" >> $out; }
+run() { python bench.py --no-cpu-baseline --no-worker-path --no-live-traffic "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); r=d.get('roofline',{}); n=d['config']['N']; print(n, d['config']['tile'], d['dtype'], d['value'], 'TF/s', d['pct_of_mfma_peak'], '% of peak; update kernel', r.get('achieved'), 'steps', d['steps'], '; one more step without the event brackets:', round(n**3/3/(d['unprofiled_ms']*1e-3)/1e12, 2), 'TF/s')" >> $out; }
 run --N 65536 --tile 1024
 run --N 32768 --tile 1024
 run --N 32768 --tile 512
