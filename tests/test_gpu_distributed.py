@@ -55,7 +55,7 @@ def test_pxq_rehearsal_on_one_gpu(P, Q, N, B, dtype, cham, orc):
     ch.CHAMELEON_Desc_Destroy(full)
 
 
-@pytest.mark.parametrize("N,dtype,tol", [(65536, "f64", 1e-13), (131072, "f32", 5e-5)])
+@pytest.mark.parametrize("N,dtype,tol", [(65536, "f64", 1e-13)])  # (config 5, N=131072 fp32: scripts/rehearse_full_size.py f32 -- 20 s)
 def test_baseline_configs_4_and_5_partitioned_for_8_gpus_at_full_size(N, dtype, tol, cham):
     """BASELINE configs 4 and 5 name a 2D block-cyclic partitioning over 8 GPUs.  There is one GPU here: the 4 x 2 walker of
     all eight ranks (threads, stream-ordered copies, no device synchronisation: chol_dist_rehearse) at the FULL size, the

@@ -181,18 +181,12 @@ def test_config3_matches_the_oracle_entry_by_entry(cham, orc):
     ch.CHAMELEON_Desc_Destroy(d)
 
 
-@pytest.mark.parametrize("N,B,dtype,trail,tol", [(65536, 1024, "f64", 8, 1e-12), (131072, 1024, "f32", 4, 1e-4)])
-def test_configs_4_and_5_trailing_tiles_match_the_oracle(cham, orc, N, B, dtype, trail, tol):
-    """BASELINE configs 4-5 at full size, the END of the run (the chain-bound, counter-linked waves): the trailing
-    `trail` x `trail` tiles of the factor are the Cholesky factor of the Schur complement  S = A22 - L21 L21^T.
-    L21 (the factor's last tile rows, downloaded) and A22 (the oracle's generator at that position of the order-N
-    matrix) give S on the host in fp64; the oracle factors it; entry by entry against the GPU's trailing tiles."""
-    ch = cham
-    dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
+def _trailing_tiles_match_the_oracle(ch, orc, d, N, B, dtype, trail, tol):
+    """The END of the run (the chain-bound, counter-linked waves): the trailing `trail` x `trail` tiles of the factor are
+    the Cholesky factor of the Schur complement  S = A22 - L21 L21^T.  L21 (the factor's last tile rows, downloaded) and
+    A22 (the oracle's generator at that position of the order-N matrix) give S on the host in fp64; the oracle factors
+    it; entry by entry against the GPU's trailing tiles."""
     nt, n2 = N // B, trail * B
-    d = full_desc(ch, N, B, dt)
-    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
-    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
     first = nt - trail
     S = orc.tile_to_lapack(orc.plgsy_tiles_lower_at(trail, B, float(N), 42, N, first), n2, B)  # A22, lower tiles filled
     S = np.asfortranarray(np.tril(S) + np.tril(S, -1).T)
@@ -220,19 +214,11 @@ def test_configs_4_and_5_trailing_tiles_match_the_oracle(cham, orc, N, B, dtype,
             diff = np.tril(got) - ref if I == J else got - ref
             worst = max(worst, np.abs(diff).max() / scale)
     assert worst <= tol, worst
-    ch.CHAMELEON_Desc_Destroy(d)
 
 
-@pytest.mark.parametrize("N,B,dtype,lead,tol", [(65536, 1024, "f64", 8192, 1e-12), (131072, 1024, "f32", 4096, 1e-4)])
-def test_configs_4_and_5_leading_block_matches_the_oracle(cham, orc, N, B, dtype, lead, tol):
-    """BASELINE configs 4-5 at full size: the leading `lead` x `lead` block of the factor, entry by entry, against
-    the oracle's factorisation of the leading block of the same (order-N) matrix; the trailing tiles by the test above,
-    the rest by the residual."""
-    ch = cham
-    dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
-    d = full_desc(ch, N, B, dt)
-    ch.CHAMELEON_dplgsy_Tile(float(N), ch.ChamLower, d, 42)
-    assert ch.CHAMELEON_dpotrf_Tile(ch.ChamLower, d) == 0
+def _leading_block_matches_the_oracle(ch, orc, d, N, B, dtype, lead, tol):
+    """The leading `lead` x `lead` block of the factor, entry by entry, against the oracle's factorisation of the leading
+    block of the same (order-N) matrix."""
     if dtype == "f32":
         T = orc.plgsy_tiles_lower(lead // B, B, float(N), 42, order=N).astype(np.float32)
         assert orc.tiled_potrf(T, lead // B, B) == 0
@@ -246,14 +232,15 @@ def test_configs_4_and_5_leading_block_matches_the_oracle(cham, orc, N, B, dtype
                 assert np.abs(diff).max() / scale <= tol, (I, J)
     else:
         _compare_leading_tiles(ch, orc, d, N, B, lead // B, tol)
-    ch.CHAMELEON_Desc_Destroy(d)
 
 
-@pytest.mark.parametrize("N,B,dtype,tol", [(65536, 1024, "f64", 1e-13), (65536, 1024, "f32", 5e-5),
-                                           (131072, 1024, "f32", 5e-5)])
-def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
-    """BASELINE configs 4 (N=65536 fp64) and 5 (N=131072 fp32, 64 GiB) in full on one GPU: factor,
-    residual of the regenerated matrix, positive finite diagonal, untouched strictly-upper tile."""
+@pytest.mark.parametrize("N,B,dtype,tol,lead,trail,tol_l", [(65536, 1024, "f64", 1e-13, 8192, 8, 1e-12), (65536, 1024, "f32", 5e-5, 0, 0, 0.0),
+                                                            (131072, 1024, "f32", 5e-5, 4096, 4, 1e-4)])
+def test_baseline_configs_4_and_5_at_full_size(cham, orc, N, B, dtype, tol, lead, trail, tol_l):
+    """BASELINE configs 4 (N=65536 fp64) and 5 (N=131072 fp32, 64 GiB) in full on one GPU, ONE factorisation each:
+    residual of the regenerated matrix, positive finite diagonal, untouched strictly-upper tile; the leading block
+    entry by entry against the oracle's factorisation of the leading block of the same order-N matrix; the trailing
+    tiles -- the chain-bound end of the run -- through the Schur complement (the rest of the factor: the residual)."""
     ch = cham
     dt = ch.ChamRealDouble if dtype == "f64" else ch.ChamRealFloat
     d = full_desc(ch, N, B, dt)
@@ -264,6 +251,10 @@ def test_baseline_config_sizes_properties(cham, N, B, dtype, tol):
     assert np.array_equal(d.download_tile(3, 40), upper_before)
     t = d.download_tile(N // B - 1, N // B - 1)
     assert np.isfinite(np.tril(t)).all() and np.diag(t).min() > 0
+    if lead:
+        _leading_block_matches_the_oracle(ch, orc, d, N, B, dtype, lead, tol_l)
+        _trailing_tiles_match_the_oracle(ch, orc, d, N, B, dtype, trail, tol_l)
+    ch.CHAMELEON_Desc_Destroy(d)
 
 
 @pytest.mark.parametrize("N,B", [(1024, 256), (2048, 512), (1000, 192)])
