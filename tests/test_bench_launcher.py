@@ -63,3 +63,25 @@ def test_self_launch_ends_a_run_whose_rank_died():
     assert rc != 0 and line["value"] is None
     assert line["failed_rank"] == 1 and line["exit_status"] == 17 and line["last_seen"].startswith("warmup")
     assert dt < 300
+
+
+@pytest.mark.gpu
+def test_bench_measures_the_update_kernels_hbm_traffic_in_the_run():
+    """bench.py: roofline.traffic comes from two child passes under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE) of the same
+    workload, not from a committed file.  Small workload here; the figure must be of the order of the kernel-level
+    algorithmic bytes (every tile update reads its C tile and two operand tiles and writes C)."""
+    import argparse
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = argparse.Namespace(N=8192, tile=512, dtype="f64", seed=42)
+    got = bench.live_pmc_traffic(a, budget_s=200.0)
+    assert got is not None, "rocprofv3 --pmc child passes failed"
+    per_launch, launches, note = got
+    assert launches > 0 and "measured in this run" in note
+    nt = 8192 // 512
+    tile_updates = 2 * sum((nt - 1 - k) * (nt - k) // 2 for k in range(nt))  # two factorisations per child
+    algorithmic = 4.0 * 512 * 512 * 8 * tile_updates / launches
+    assert 0.3 * algorithmic <= per_launch <= 3.0 * algorithmic, (per_launch, algorithmic)
